@@ -1,0 +1,192 @@
+/*
+ * ptrwm.h -- C ABI of the MI355X (gfx950) PT-RWM sampling engine.
+ *
+ * This is the drop-in boundary for the per-step hot loop of the reference
+ * (aidanmrli/rwm-pt-pytorch):
+ *
+ *   algorithms/rwm_gpu_optimized.py:289-336   _single_step_ultra_fused
+ *   algorithms/rwm_gpu_optimized.py:402-488   generate_samples (the `for i in range(total_steps)` loop)
+ *   algorithms/pt_rwm_gpu_optimized.py:541-574 step
+ *   algorithms/pt_rwm_gpu_optimized.py:594-633 _attempt_all_swaps
+ *   algorithms/pt_rwm_gpu_optimized.py:694-770 generate_samples
+ *
+ * The reference has no FFI of its own (it is pure Python on torch tensors); the
+ * binding a maintainer adds is the ctypes stub shown in INTEGRATION.md.  All
+ * pointers named "device" are raw HIP device pointers (e.g. torch
+ * `tensor.data_ptr()` on a ROCm build); `stream` is a `hipStream_t` passed as
+ * `void*` (torch: `torch.cuda.current_stream().cuda_stream`).  Nothing here
+ * retains a pointer past the call, allocates device memory, or synchronises:
+ * every entry point only enqueues kernels on `stream`.
+ *
+ * All entry points return 0 on success or a negative PTRWM_E_* code; no C++
+ * exception crosses this boundary.
+ */
+#ifndef PTRWM_H
+#define PTRWM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTRWM_ABI_VERSION 1
+#define PTRWM_MAX_DIM 104  /* dim-vector lives in VGPRs; widest compiled variant */
+#define PTRWM_MAX_TEMPS 64 /* one ladder must fit one 64-lane wavefront */
+
+/* ---- status codes ------------------------------------------------------ */
+enum {
+  PTRWM_OK = 0,
+  PTRWM_E_NULL = -1,        /* required pointer is NULL */
+  PTRWM_E_DIM = -2,         /* dim outside [1, PTRWM_MAX_DIM] or invalid for the target */
+  PTRWM_E_TEMPS = -3,       /* n_temps outside [1, PTRWM_MAX_TEMPS] */
+  PTRWM_E_KIND = -4,        /* unknown target / proposal kind */
+  PTRWM_E_ARG = -5,         /* other invalid argument (negative counts, swap_every < 1 ...) */
+  PTRWM_E_STRUCT = -6,      /* struct_size does not match this ABI version */
+  PTRWM_E_LAUNCH = -7,      /* HIP reported a launch error */
+  PTRWM_E_NOVARIANT = -8    /* (target, proposal, dim) variant not compiled into this build */
+};
+
+/* ---- target densities ---------------------------------------------------
+ * Each kind restates the fp32 `log_density` of one reference class. */
+enum {
+  /* target_distributions/multimodal_torch.py:470-510 RoughCarpetDistributionTorch
+   *   p[0..2] = modes, p[3..5] = log weights, p[6] = log_jacobian (0 if unscaled)
+   *   vec0 = scaling_factors[dim] or NULL */
+  PTRWM_TARGET_ROUGH_CARPET = 0,
+  /* multimodal_torch.py:173-242 ThreeMixtureDistributionTorch (cov = I)
+   *   p[0..2] = log_norm_const_k + log_mixing_weight_k (+ log_jacobian if scaled)
+   *   vec0 = means[3*dim] (row-major [3][dim]); vec1 = scaling_factors[dim] or NULL */
+  PTRWM_TARGET_THREE_MIXTURE = 1,
+  /* rosenbrock_torch.py:67-84 FullRosenbrockTorch: p[0]=a, p[1]=b, vec0 = mu[dim-1] */
+  PTRWM_TARGET_FULL_ROSENBROCK = 2,
+  /* rosenbrock_torch.py:194-210 EvenRosenbrockTorch: p[0]=a, p[1]=b, vec0 = mu[dim/2] */
+  PTRWM_TARGET_EVEN_ROSENBROCK = 3,
+  /* rosenbrock_torch.py:312-351 HybridRosenbrockTorch: p[0]=a, p[1]=b, p[2]=mu,
+   *   ip[0]=n1, ip[1]=n2, dim = 1 + n2*(n1-1) */
+  PTRWM_TARGET_HYBRID_ROSENBROCK = 4,
+  /* iid_product_torch.py:52-91 IIDGammaTorch: p[0]=shape, p[1]=scale, p[2]=log_norm_const (dim * 1d) */
+  PTRWM_TARGET_IID_GAMMA = 5,
+  /* iid_product_torch.py:188-229 IIDBetaTorch: p[0]=alpha, p[1]=beta, p[2]=log_norm_const (dim * 1d) */
+  PTRWM_TARGET_IID_BETA = 6,
+  PTRWM_TARGET_COUNT = 7
+};
+
+typedef struct ptrwm_target_desc {
+  int32_t kind;
+  int32_t dim;
+  float p[12];
+  int32_t ip[4];
+  const float *vec0; /* device, see kind */
+  const float *vec1; /* device, see kind */
+} ptrwm_target_desc;
+
+/* ---- proposal increments -------------------------------------------------
+ * increment[d] for the replica at temperature t. */
+enum {
+  /* proposal_distributions/normal.py:33-36,46-55 and pt_rwm_gpu_optimized.py:445-455,576-592
+   *   inc_d = temp_scale[t] * z_d,  z ~ N(0,1) */
+  PTRWM_PROPOSAL_NORMAL = 0,
+  /* proposal_distributions/laplace.py:24-37,46-69
+   *   u = U[0,1) - 0.5;  inc_d = -(dim_scale[d]*temp_scale[t]) * sign(u) * log1p(max(-2|u|, -0.999999)) */
+  PTRWM_PROPOSAL_LAPLACE = 1,
+  /* proposal_distributions/uniform.py:27-37,47-73
+   *   g = N(0,I_dim); n = |g| (1 if <= 1e-12); inc = g/n * temp_scale[t] * U^{inv_dim} */
+  PTRWM_PROPOSAL_UNIFORM_RADIUS = 2,
+  PTRWM_PROPOSAL_COUNT = 3
+};
+
+typedef struct ptrwm_proposal_desc {
+  int32_t kind;
+  float inv_dim;           /* UNIFORM_RADIUS: 1/dim as the reference stores it */
+  const float *temp_scale; /* device [n_temps] */
+  const float *dim_scale;  /* device [dim], LAPLACE only (NULL otherwise) */
+} ptrwm_proposal_desc;
+
+/* ---- swap semantics (pt_rwm_gpu_optimized.py:594-633) ---- */
+enum {
+  PTRWM_SWAP_EXCHANGE = 0,       /* rows j and k trade places (algorithms/pt_rwm.py:141-150) */
+  PTRWM_SWAP_REFERENCE_COPY = 1  /* row j <- row k, row k unchanged: what
+                                    fused_swap_execution_no_clone (pt_rwm_gpu_optimized.py:51-59) does */
+};
+enum {
+  PTRWM_ORDER_SEQUENTIAL = 0, /* j = 0..T-2 in order, each sees the previous outcome (reference) */
+  PTRWM_ORDER_EVEN_ODD = 1    /* n-th swap event (0-based) attempts the disjoint pairs j == n (mod 2) */
+};
+
+/* Number of raw random numbers one MH proposal consumes from `ext_prop`
+ * (NORMAL: dim normals; LAPLACE: dim uniforms in [0,1); UNIFORM_RADIUS: dim
+ * normals then one uniform). */
+int32_t ptrwm_ext_raw_per_step(int32_t proposal_kind, int32_t dim);
+
+typedef struct ptrwm_run_args {
+  uint32_t struct_size; /* sizeof(ptrwm_run_args) */
+  int32_t n_temps;
+  int64_t n_chains;     /* independent ladders (RWM: independent chains) on this device */
+  int64_t chain_offset; /* global id of local chain 0: the Philox subsequence, so results do not
+                           depend on how chains are sharded over devices */
+  /* state, device, updated in place */
+  float *state; /* [n_chains, n_temps, dim] */
+  float *logp;  /* [n_chains, n_temps] log-density of `state` */
+  const float *beta; /* [n_temps] inverse temperatures, beta[0] is the cold chain */
+  /* statistics, device, accumulated (+=); any may be NULL */
+  int64_t *n_accept;    /* [n_chains, n_temps] MH acceptances at steps with step_counter > burn_in */
+  double *sq_jump;      /* [n_chains, n_temps] sum of |x_t - x_{t-1}|^2 over those steps (swap moves included) */
+  int64_t *swap_accept; /* [n_chains, n_temps] accepted swaps of pair (t, t+1); column n_temps-1 unused */
+  int64_t *last_swap_ordinal; /* [n_chains, n_temps] max 1-based attempt ordinal at which pair t accepted */
+  /* schedule: this call performs steps step0 .. step0+n_steps-1 (0-based); step i has
+   * step_counter = i+1.  Swaps happen after the MH move of a step when
+   * step_counter % swap_every == 0 and step_counter > burn_in (pt_rwm_gpu_optimized.py:544,570). */
+  int64_t step0;
+  int64_t n_steps;
+  int64_t burn_in;
+  int32_t swap_every;
+  int32_t swap_mode;
+  int32_t swap_order;
+  int32_t reserved0;
+  uint64_t seed; /* Philox4x32-10 key */
+  /* external randoms (test / fixture mode); all NULL => in-kernel Philox */
+  const float *ext_prop;   /* [n_steps, n_chains, n_temps, ptrwm_ext_raw_per_step()] */
+  const float *ext_u;      /* [n_steps, n_chains, n_temps] accept uniforms */
+  const float *ext_swap_u; /* [n_swap_events_in_call, n_chains, n_temps-1] */
+  /* optional per-step outputs */
+  float *trace;        /* [trace_rows, trace_chains, trace_temps, dim] state after each step of this call */
+  float *trace_logp;   /* [trace_rows, trace_chains, trace_temps] */
+  int64_t trace_chains; /* first trace_chains local chains are traced */
+  int32_t trace_temps;  /* first trace_temps temperatures are traced (1 = cold chain only) */
+  int32_t reserved1;
+  int64_t trace_row0;   /* row written by the first step of this call */
+  uint8_t *accept_flags; /* [n_steps, n_chains, n_temps] MH accept decision of every step, or NULL */
+} ptrwm_run_args;
+
+/* Advance every (chain, temperature) replica by n_steps Metropolis steps (with
+ * swaps) in one fused kernel launch on `stream`. */
+int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *proposal,
+                  const ptrwm_run_args *args, void *stream);
+
+/* out[i] = log_density(x[i, :]) for i < n; x is device [n, dim], out device [n]. */
+int32_t ptrwm_logdensity(const ptrwm_target_desc *target, const float *x, float *out, int64_t n,
+                         void *stream);
+
+/* Proposal increments only (unit parity of the three samplers):
+ * out[i, t, :] for i < n.  If ext_raw != NULL it is device [n, n_temps, raw_per_step]
+ * and the transform is applied to it; otherwise Philox(seed) with the same
+ * counter layout as ptrwm_run at step index i, chain id 0.. */
+int32_t ptrwm_propose(const ptrwm_proposal_desc *proposal, int32_t dim, int32_t n_temps, int64_t n,
+                      const float *ext_raw, uint64_t seed, float *out, void *stream);
+
+/* Raw Philox4x32-10 blocks: out[i*4 .. i*4+3] = philox(counter = (c0 + i, c1, c2, c3), key = seed).
+ * out is device [n, 4] uint32.  Known-answer tested against the Random123 vectors. */
+int32_t ptrwm_philox_raw(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                         int64_t n, uint32_t *out, void *stream);
+
+/* 1 if the (target, proposal, dim) variant is compiled in, else 0. */
+int32_t ptrwm_has_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim);
+
+int32_t ptrwm_abi_version(void);
+const char *ptrwm_strerror(int32_t code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTRWM_H */

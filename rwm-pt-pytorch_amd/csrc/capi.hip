@@ -1,0 +1,287 @@
+// C ABI of the PT-RWM engine (include/ptrwm.h): argument validation, variant
+// dispatch and launch.  No allocation, no synchronisation, no retained pointers.
+#include "../../include/ptrwm.h"
+#include "variants.h"
+
+namespace ptrwm {
+
+static const TargetVariants *target_variants(int kind) {
+  switch (kind) {
+    case PTRWM_TARGET_ROUGH_CARPET: return &rough_carpet_variants();
+    case PTRWM_TARGET_THREE_MIXTURE: return &three_mixture_variants();
+    case PTRWM_TARGET_FULL_ROSENBROCK: return &full_rosenbrock_variants();
+    case PTRWM_TARGET_EVEN_ROSENBROCK: return &even_rosenbrock_variants();
+    case PTRWM_TARGET_HYBRID_ROSENBROCK: return &hybrid_rosenbrock_variants();
+    case PTRWM_TARGET_IID_GAMMA: return &iid_gamma_variants();
+    case PTRWM_TARGET_IID_BETA: return &iid_beta_variants();
+    default: return nullptr;
+  }
+}
+
+static int check_target(const ptrwm_target_desc *t) {
+  if (t == nullptr) return PTRWM_E_NULL;
+  if (t->kind < 0 || t->kind >= PTRWM_TARGET_COUNT) return PTRWM_E_KIND;
+  if (t->dim < 1 || t->dim > PTRWM_MAX_DIM) return PTRWM_E_DIM;
+  switch (t->kind) {
+    case PTRWM_TARGET_THREE_MIXTURE:
+      if (t->vec0 == nullptr) return PTRWM_E_NULL;
+      break;
+    case PTRWM_TARGET_FULL_ROSENBROCK:
+      if (t->dim < 2) return PTRWM_E_DIM;
+      if (t->vec0 == nullptr) return PTRWM_E_NULL;
+      break;
+    case PTRWM_TARGET_EVEN_ROSENBROCK:
+      if (t->dim < 2 || (t->dim & 1)) return PTRWM_E_DIM;
+      if (t->vec0 == nullptr) return PTRWM_E_NULL;
+      break;
+    case PTRWM_TARGET_HYBRID_ROSENBROCK:
+      if (t->ip[0] < 2 || t->ip[1] < 1) return PTRWM_E_ARG;
+      if (t->dim != 1 + t->ip[1] * (t->ip[0] - 1)) return PTRWM_E_DIM;
+      break;
+    default:
+      break;
+  }
+  return PTRWM_OK;
+}
+
+static TParams make_tparams(const ptrwm_target_desc *t) {
+  TParams tp;
+  for (int i = 0; i < 12; ++i) tp.p[i] = t->p[i];
+  for (int i = 0; i < 4; ++i) tp.ip[i] = t->ip[i];
+  tp.vec0 = t->vec0;
+  tp.vec1 = t->vec1;
+  tp.mask[0] = tp.mask[1] = 0;
+  if (t->kind == PTRWM_TARGET_ROUGH_CARPET) {
+    // fold the per-dimension -log(sqrt(2 pi)) of multimodal_torch.py:500 into one constant
+    tp.p[7] = -(float)t->dim * 0.91893853320467274178f;
+  }
+  if (t->kind == PTRWM_TARGET_HYBRID_ROSENBROCK) {
+    const int blk = t->ip[0] - 1;
+    for (int i = 1; i < t->dim; ++i)
+      if ((i - 1) % blk == 0) tp.mask[i >> 6] |= (1ull << (i & 63));
+  }
+  return tp;
+}
+
+__global__ void philox_raw_kernel(uint32_t *__restrict__ out, long long n, uint32_t c0, uint32_t c1, uint32_t c2,
+                                  uint32_t c3, uint32_t k0, uint32_t k1) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32x4 r = philox4x32_10(c0 + (uint32_t)i, c1, c2, c3, k0, k1);
+  out[4 * i + 0] = r.x;
+  out[4 * i + 1] = r.y;
+  out[4 * i + 2] = r.z;
+  out[4 * i + 3] = r.w;
+}
+
+template <template <int> class Proposal>
+static hipError_t launch_propose(int wi, float *out, long long n, int D, int T, const float *ts, const PParams &pp,
+                                 const float *ext_raw, int n_raw, unsigned k0, unsigned k1, hipStream_t st) {
+  const long long tot = n * T;
+  const dim3 grid((unsigned)((tot + kBlockThreads - 1) / kBlockThreads)), block(kBlockThreads);
+  int idx = 0;
+#define PTRWM_X_PROPOSE(W, E)                                                                              \
+  if (wi == idx++)                                                                                         \
+    hipLaunchKernelGGL((ptrwm_propose_kernel<Proposal<W>, W>), grid, block, 0, st, out, n, D, T, ts, pp,   \
+                       ext_raw, n_raw, k0, k1);
+  PTRWM_WIDTHS(PTRWM_X_PROPOSE)
+#undef PTRWM_X_PROPOSE
+  return hipGetLastError();
+}
+
+}  // namespace ptrwm
+
+using namespace ptrwm;
+
+extern "C" {
+
+int32_t ptrwm_abi_version(void) { return PTRWM_ABI_VERSION; }
+
+const char *ptrwm_strerror(int32_t code) {
+  switch (code) {
+    case PTRWM_OK: return "ok";
+    case PTRWM_E_NULL: return "required pointer is NULL";
+    case PTRWM_E_DIM: return "dim out of range or invalid for this target";
+    case PTRWM_E_TEMPS: return "n_temps out of range (1..64)";
+    case PTRWM_E_KIND: return "unknown target or proposal kind";
+    case PTRWM_E_ARG: return "invalid argument";
+    case PTRWM_E_STRUCT: return "struct_size mismatch (ABI version)";
+    case PTRWM_E_LAUNCH: return "HIP launch error";
+    case PTRWM_E_NOVARIANT: return "variant not compiled";
+    default: return "unknown error";
+  }
+}
+
+int32_t ptrwm_ext_raw_per_step(int32_t proposal_kind, int32_t dim) {
+  switch (proposal_kind) {
+    case PTRWM_PROPOSAL_NORMAL: return dim;
+    case PTRWM_PROPOSAL_LAPLACE: return dim;
+    case PTRWM_PROPOSAL_UNIFORM_RADIUS: return dim + 1;
+    default: return PTRWM_E_KIND;
+  }
+}
+
+int32_t ptrwm_has_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim) {
+  if (target_kind < 0 || target_kind >= PTRWM_TARGET_COUNT) return 0;
+  if (proposal_kind < 0 || proposal_kind >= PTRWM_PROPOSAL_COUNT) return 0;
+  const int dpi = width_index_for_dim(dim);
+  if (dim < 1 || dpi < 0) return 0;
+  return target_variants(target_kind)->run[proposal_kind][dpi] != nullptr ? 1 : 0;
+}
+
+int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *proposal, const ptrwm_run_args *args,
+                  void *stream) {
+  if (proposal == nullptr || args == nullptr) return PTRWM_E_NULL;
+  if (int rc = check_target(target)) return rc;
+  if (args->struct_size != sizeof(ptrwm_run_args)) return PTRWM_E_STRUCT;
+  if (proposal->kind < 0 || proposal->kind >= PTRWM_PROPOSAL_COUNT) return PTRWM_E_KIND;
+  if (args->n_temps < 1 || args->n_temps > PTRWM_MAX_TEMPS) return PTRWM_E_TEMPS;
+  if (args->n_chains < 0 || args->n_steps < 0 || args->step0 < 0 || args->burn_in < 0 || args->swap_every < 1)
+    return PTRWM_E_ARG;
+  if (args->swap_mode != PTRWM_SWAP_EXCHANGE && args->swap_mode != PTRWM_SWAP_REFERENCE_COPY) return PTRWM_E_ARG;
+  if (args->swap_order != PTRWM_ORDER_SEQUENTIAL && args->swap_order != PTRWM_ORDER_EVEN_ODD) return PTRWM_E_ARG;
+  if (args->state == nullptr || args->logp == nullptr || args->beta == nullptr || proposal->temp_scale == nullptr)
+    return PTRWM_E_NULL;
+  if (proposal->kind == PTRWM_PROPOSAL_LAPLACE && proposal->dim_scale == nullptr) return PTRWM_E_NULL;
+  const bool ext = args->ext_prop != nullptr;
+  if (ext && args->ext_u == nullptr) return PTRWM_E_NULL;
+  if (args->trace != nullptr && (args->trace_chains < 1 || args->trace_temps < 1 || args->trace_row0 < 0 ||
+                                 args->trace_temps > args->n_temps || args->trace_chains > args->n_chains))
+    return PTRWM_E_ARG;
+  if (args->n_chains == 0 || args->n_steps == 0) return PTRWM_OK;
+
+  const int dpi = width_index_for_dim(target->dim);
+  if (dpi < 0) return PTRWM_E_DIM;
+  const RunLaunchFn fn = target_variants(target->kind)->run[proposal->kind][dpi];
+  if (fn == nullptr) return PTRWM_E_NOVARIANT;
+
+  const long long se = args->swap_every;
+  const bool full = ext || args->trace != nullptr || args->accept_flags != nullptr;
+  // swap events before step_counter sc = multiples m*se with burn_in < m*se <= sc
+  auto events_upto = [&](long long sc) -> long long {
+    const long long e = sc / se - args->burn_in / se;
+    return e > 0 ? e : 0;
+  };
+  if (ext && args->n_temps > 1 && events_upto(args->step0 + args->n_steps) > events_upto(args->step0) &&
+      args->ext_swap_u == nullptr)
+    return PTRWM_E_NULL;
+
+  KArgs k;
+  k.state = args->state;
+  k.logp = args->logp;
+  k.beta = args->beta;
+  k.temp_scale = proposal->temp_scale;
+  k.n_accept = (long long *)args->n_accept;
+  k.sq_jump = args->sq_jump;
+  k.swap_accept = (long long *)args->swap_accept;
+  k.last_swap_ordinal = (long long *)args->last_swap_ordinal;
+  k.n_chains = args->n_chains;
+  k.chain_offset = args->chain_offset;
+  k.n_temps = args->n_temps;
+  k.dim = target->dim;
+  k.swap_every = args->swap_every;
+  k.swap_mode = args->swap_mode;
+  k.swap_order = args->swap_order;
+  k.chains_per_wave = 64 / args->n_temps;
+  k.k0 = (unsigned)(args->seed & 0xffffffffull);
+  k.k1 = (unsigned)(args->seed >> 32);
+  k.tp = make_tparams(target);
+  k.pp.dim_scale = proposal->dim_scale;
+  k.pp.inv_dim = proposal->inv_dim;
+  k.full.trace = args->trace;
+  k.full.trace_logp = args->trace_logp;
+  k.full.trace_chains = args->trace != nullptr ? args->trace_chains : 0;
+  k.full.trace_temps = args->trace_temps;
+  k.full.n_raw_ext = ptrwm_ext_raw_per_step(proposal->kind, target->dim);
+
+  const long long n_waves = (args->n_chains + k.chains_per_wave - 1) / k.chains_per_wave;
+  const long long n_blocks = (n_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (n_blocks > 0x7fffffffll) return PTRWM_E_ARG;
+
+  // One launch covers at most kMaxStepsPerLaunch steps (32-bit in-kernel counters, bounded kernel
+  // run time); longer requests become back-to-back launches on the same stream.
+  const long long kMaxStepsPerLaunch = 1 << 20;
+  const long long reps = args->n_chains * args->n_temps;
+  const long long raw = k.full.n_raw_ext;
+  long long done = 0;
+  while (done < args->n_steps) {
+    const long long step0 = args->step0 + done;
+    const long long n = (args->n_steps - done < kMaxStepsPerLaunch) ? args->n_steps - done : kMaxStepsPerLaunch;
+    const long long ev0 = events_upto(step0);
+    k.step0 = step0;
+    k.n_steps = (int)n;
+    const long long burn_left = args->burn_in - step0;
+    k.burn_left = burn_left <= 0 ? 0 : (burn_left > n ? (int)n : (int)burn_left);
+    k.first_swap_event = ev0;
+    k.steps_to_swap = (int)(se - step0 % se);
+    k.full.ext_prop = ext ? args->ext_prop + done * reps * raw : nullptr;
+    k.full.ext_u = ext ? args->ext_u + done * reps : nullptr;
+    k.full.ext_swap_u = (ext && args->ext_swap_u != nullptr)
+                            ? args->ext_swap_u + (ev0 - events_upto(args->step0)) * args->n_chains * (args->n_temps - 1)
+                            : nullptr;
+    k.full.accept_flags = args->accept_flags != nullptr ? args->accept_flags + done * reps : nullptr;
+    k.full.trace_row0 = args->trace_row0 + done;
+    const hipError_t err = fn(k, (unsigned)n_blocks, full, (hipStream_t)stream);
+    if (err != hipSuccess) return PTRWM_E_LAUNCH;
+    done += n;
+  }
+  return PTRWM_OK;
+}
+
+int32_t ptrwm_logdensity(const ptrwm_target_desc *target, const float *x, float *out, int64_t n, void *stream) {
+  if (int rc = check_target(target)) return rc;
+  if (n < 0) return PTRWM_E_ARG;
+  if (n == 0) return PTRWM_OK;
+  if (x == nullptr || out == nullptr) return PTRWM_E_NULL;
+  const int dpi = width_index_for_dim(target->dim);
+  if (dpi < 0) return PTRWM_E_DIM;
+  const LogpLaunchFn fn = target_variants(target->kind)->logp[dpi];
+  if (fn == nullptr) return PTRWM_E_NOVARIANT;
+  const hipError_t err = fn(x, out, n, target->dim, make_tparams(target), (hipStream_t)stream);
+  return err == hipSuccess ? PTRWM_OK : PTRWM_E_LAUNCH;
+}
+
+int32_t ptrwm_propose(const ptrwm_proposal_desc *proposal, int32_t dim, int32_t n_temps, int64_t n,
+                      const float *ext_raw, uint64_t seed, float *out, void *stream) {
+  if (proposal == nullptr) return PTRWM_E_NULL;
+  if (proposal->kind < 0 || proposal->kind >= PTRWM_PROPOSAL_COUNT) return PTRWM_E_KIND;
+  if (dim < 1 || dim > PTRWM_MAX_DIM) return PTRWM_E_DIM;
+  if (n_temps < 1 || n_temps > PTRWM_MAX_TEMPS) return PTRWM_E_TEMPS;
+  if (n < 0) return PTRWM_E_ARG;
+  if (n == 0) return PTRWM_OK;
+  if (out == nullptr || proposal->temp_scale == nullptr) return PTRWM_E_NULL;
+  if (proposal->kind == PTRWM_PROPOSAL_LAPLACE && proposal->dim_scale == nullptr) return PTRWM_E_NULL;
+  const int dpi = width_index_for_dim(dim);
+  if (dpi < 0) return PTRWM_E_DIM;
+  PParams pp;
+  pp.dim_scale = proposal->dim_scale;
+  pp.inv_dim = proposal->inv_dim;
+  const int n_raw = ptrwm_ext_raw_per_step(proposal->kind, dim);
+  const unsigned k0 = (unsigned)(seed & 0xffffffffull), k1 = (unsigned)(seed >> 32);
+  hipError_t err;
+  switch (proposal->kind) {
+    case PTRWM_PROPOSAL_NORMAL:
+      err = launch_propose<NormalProposal>(dpi, out, n, dim, n_temps, proposal->temp_scale, pp, ext_raw, n_raw, k0, k1, (hipStream_t)stream);
+      break;
+    case PTRWM_PROPOSAL_LAPLACE:
+      err = launch_propose<LaplaceProposal>(dpi, out, n, dim, n_temps, proposal->temp_scale, pp, ext_raw, n_raw, k0, k1, (hipStream_t)stream);
+      break;
+    default:
+      err = launch_propose<UniformRadiusProposal>(dpi, out, n, dim, n_temps, proposal->temp_scale, pp, ext_raw, n_raw, k0, k1, (hipStream_t)stream);
+      break;
+  }
+  return err == hipSuccess ? PTRWM_OK : PTRWM_E_LAUNCH;
+}
+
+int32_t ptrwm_philox_raw(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int64_t n, uint32_t *out,
+                         void *stream) {
+  if (n < 0) return PTRWM_E_ARG;
+  if (n == 0) return PTRWM_OK;
+  if (out == nullptr) return PTRWM_E_NULL;
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(philox_raw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, (long long)n, c0, c1, c2,
+                     c3, (unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32));
+  return hipGetLastError() == hipSuccess ? PTRWM_OK : PTRWM_E_LAUNCH;
+}
+
+}  // extern "C"

@@ -1,0 +1,354 @@
+// The fused PT-RWM kernel: one (chain, temperature) replica per thread, the
+// temperatures of one chain contiguous inside one 64-lane wavefront.
+//
+// Replaces, per launch, n_steps iterations of
+//   algorithms/rwm_gpu_optimized.py:289-336    (_single_step_ultra_fused, T = 1)
+//   algorithms/pt_rwm_gpu_optimized.py:541-574 (step) + :594-633 (_attempt_all_swaps)
+// with the replica's dim-vector, log-density and counters held in registers for
+// the whole launch: HBM is touched once to load and once to store the state.
+//
+// Lane map: lane = cw * T + t  (cw = chain slot within the wave, t = temperature),
+// chains_per_wave = 64 / T; lanes >= chains_per_wave*T idle (only when T does
+// not divide 64).  Swaps are therefore pure cross-lane traffic (ds_bpermute),
+// never HBM.
+#pragma once
+#include "philox.h"
+#include "proposals.h"
+#include "targets.h"
+
+namespace ptrwm {
+
+constexpr int kBlockThreads = 256;
+constexpr int kWavesPerBlock = kBlockThreads / 64;
+
+// Arguments only the fixture / trace variant of the kernel (FULL = true) reads.  Keeping them out
+// of the production variant keeps its wave-uniform state inside the 100-odd SGPRs of a wave.
+struct FullArgs {
+  const float *__restrict__ ext_prop;
+  const float *__restrict__ ext_u;
+  const float *__restrict__ ext_swap_u;
+  float *__restrict__ trace;
+  float *__restrict__ trace_logp;
+  unsigned char *__restrict__ accept_flags;
+  long long trace_chains, trace_row0;
+  int trace_temps, n_raw_ext;
+};
+
+struct KArgs {
+  float *__restrict__ state;
+  float *__restrict__ logp;
+  const float *__restrict__ beta;
+  const float *__restrict__ temp_scale;
+  long long *__restrict__ n_accept;
+  double *__restrict__ sq_jump;
+  long long *__restrict__ swap_accept;
+  long long *__restrict__ last_swap_ordinal;
+  long long n_chains, chain_offset, step0;
+  long long first_swap_event;  // 0-based index (since the start of the run) of the first swap event in this call
+  int n_steps;                 // steps in this launch (the C ABI splits longer requests)
+  int burn_left;               // steps of this launch that still belong to burn-in (step_counter <= burn_in)
+  int n_temps, dim, swap_every, swap_mode, swap_order, chains_per_wave;
+  int steps_to_swap;  // steps until the next step whose step_counter is a multiple of swap_every (1 = the first step)
+  unsigned k0, k1;
+  TParams tp;
+  PParams pp;
+  FullArgs full;
+};
+
+// log swap probability exactly as fused_swap_probability_calculation evaluates it
+// (algorithms/pt_rwm_gpu_optimized.py:37-48): four products summed left to right.
+__device__ __forceinline__ float swap_log_prob(float bj, float bk, float lj, float lk) {
+  return sub_rn(sub_rn(add_rn(mul_rn(bj, lk), mul_rn(bk, lj)), mul_rn(bj, lj)), mul_rn(bk, lk));
+}
+
+// swap_random < min(1, exp(log_prob))  (:617-621).  torch.min propagates NaN and NaN compares
+// false; v_min_f32 would drop the NaN, so the clamp is written as a select instead.
+__device__ __forceinline__ bool swap_accept_test(float u, float log_prob) {
+  return (log_prob >= 0.0f) ? (u < 1.0f) : (u < hw_exp(log_prob));
+}
+
+// DP    compile-time width of the per-thread register arrays (>= dim)
+// EXACT dim == DP is known at compile time: every per-dimension predicate folds away.  Otherwise
+//       dim is a wave-uniform run-time value, re-read (opaquely) every step so the compiler tests
+//       `d < dim` with one scalar compare in place instead of hoisting DP booleans into SGPRs.
+// FULL  fixture/trace variant: external randoms, per-step trace and accept-flag outputs.
+template <bool EXACT>
+__device__ __forceinline__ int fresh_dim(int d0) {
+  if constexpr (!EXACT) asm volatile("" : "+s"(d0));
+  return d0;
+}
+
+// Register budget: the replica's x[DP] and y[DP] plus ~30 temporaries must stay in VGPRs.  Without a
+// bound hipcc hoists every Philox block of a step ahead of its consumers and lands far above that.
+constexpr int min_waves_per_simd(int dp) { return dp <= 44 ? 4 : (dp <= 64 ? 3 : 1); }
+
+template <class Target, class Proposal, int DP, bool EXACT, bool FULL>
+__global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_step_kernel(const KArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int T = a.n_temps;
+  const int D0 = EXACT ? DP : a.dim;
+  const int cpw = a.chains_per_wave;
+  const long long wave_id = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const long long chain0 = wave_id * cpw;
+  if (chain0 >= a.n_chains) return;  // wave-uniform
+
+  const int cw_raw = lane / T;
+  const int t_raw = lane - cw_raw * T;
+  const bool live = (cw_raw < cpw) && (chain0 + cw_raw < a.n_chains);
+  // idle lanes shadow replica (chain0, 0): they compute but never store and are never a shuffle source
+  const int cw = live ? cw_raw : 0;
+  const int t = live ? t_raw : 0;
+  const int base = cw * T;  // first lane of this lane's ladder
+  const long long chain = chain0 + cw;
+  const long long rep = chain * T + t;
+
+  float x[DP], y[DP];
+  {
+    const float *__restrict__ xp = a.state + rep * D0;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) x[d] = (d < D0) ? xp[d] : 0.0f;
+  }
+  float lp = a.logp[rep];
+  const float beta_t = a.beta[t];
+  const float tscale = a.temp_scale[t];
+
+  const unsigned long long gchain = (unsigned long long)(a.chain_offset + chain);
+  RngCtx rc;
+  rc.c2 = (uint32_t)gchain;
+  rc.k0 = a.k0;
+  rc.k1 = a.k1;
+  const uint32_t c3_base = (uint32_t)t | ((uint32_t)(gchain >> 32) << 12);
+
+  unsigned n_acc = 0, n_swap_acc = 0;
+  int last_event = -1;  // index within this launch of the last swap event whose pair (t, t+1) accepted
+  double sq = 0.0;
+
+  const bool ext = FULL && a.full.ext_prop != nullptr;
+  const bool trace_on =
+      FULL && live && a.full.trace != nullptr && (chain < a.full.trace_chains) && (t < a.full.trace_temps);
+  int to_swap = a.steps_to_swap;
+  int swap_in_call = 0;  // swap events already done in this launch
+  const int ev_par0 = (int)(a.first_swap_event & 1);
+  unsigned long long s = (unsigned long long)a.step0;  // 0-based global step index
+
+  for (int i = 0; i < a.n_steps; ++i, ++s) {
+    const bool count_on = i >= a.burn_left;
+    --to_swap;
+    const bool multiple = (to_swap == 0);
+    if (multiple) to_swap = a.swap_every;
+    const bool swap_due = multiple && count_on && (T > 1);
+
+    rc.c0hi = (uint32_t)(s >> 32) << 16;
+    rc.c1 = (uint32_t)s;
+    rc.c3 = c3_base | (kStreamMH << 8);
+
+    long long srep = 0;
+    const float *ext_raw = nullptr;
+    float ext_u = 0.0f;
+    if constexpr (FULL) {
+      srep = ((long long)i * a.n_chains + chain) * T + t;
+      if (ext) {
+        ext_raw = a.full.ext_prop + srep * a.full.n_raw_ext;
+        ext_u = a.full.ext_u[srep];
+      }
+    }
+
+    const float u_acc = Proposal::propose(y, x, fresh_dim<EXACT>(D0), tscale, a.pp, rc, ext_raw, ext_u);
+    const float lp_new = Target::logp(y, fresh_dim<EXACT>(D0), a.tp);
+    const int D = fresh_dim<EXACT>(D0);
+
+    // ultra_fused_mcmc_step_basic / ultra_fused_parallel_mcmc_step:
+    //   r = beta (l' - l);  accept = (r > 0) | (u < exp r)
+    const float ratio = mul_rn(beta_t, sub_rn(lp_new, lp));
+    const bool acc = (ratio > 0.0f) || (u_acc < hw_exp(ratio));
+    const float lp_mh = acc ? lp_new : lp;
+    if constexpr (FULL) {
+      if (a.full.accept_flags != nullptr && live) a.full.accept_flags[srep] = acc ? 1 : 0;
+    }
+
+    float j2 = 0.0f;
+    if (!swap_due) {
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        if (d < D) {
+          const float dl = sub_rn(y[d], x[d]);
+          j2 = fmaf(dl, dl, j2);
+          x[d] = acc ? y[d] : x[d];
+        }
+        if ((d & 7) == 7) sched_fence();
+      }
+      if (!acc) j2 = 0.0f;
+      lp = lp_mh;
+    } else {
+      // ---- temperature swaps on the post-MH log-densities (pt_rwm_gpu_optimized.py:594-633) ----
+      // src = lane whose post-MH vector ends up at this lane's temperature
+      int src = lane;
+      float my_l = lp_mh;
+      bool pair_acc = false;  // did pair (t, t+1) accept (recorded on lane t)
+      float us;
+      if (ext) {
+        us = (t < T - 1) ? a.full.ext_swap_u[((long long)swap_in_call * a.n_chains + chain) * (T - 1) + t] : 2.0f;
+      } else {
+        const u32x4 r = philox4x32_10(rc.c0hi, rc.c1, rc.c2, c3_base | (kStreamSwap << 8), rc.k0, rc.k1);
+        us = u01(r.x);
+      }
+      if (a.swap_order == PTRWM_ORDER_SEQUENTIAL) {
+        if (a.swap_mode == PTRWM_SWAP_EXCHANGE) {
+          // The sweep j = 0..T-2 carries one state upward: at pair j the state now
+          // at position j (carried) meets the still-untouched state of position j+1.
+          // Every lane of the ladder replays the scan from the original values
+          // (no dependent shuffles) and keeps what lands on its own position.
+          float car_l = __shfl(my_l, base, 64);
+          int car_i = base;
+          const float l_own = my_l;
+          for (int j = 0; j < T - 1; ++j) {
+            const float lk = __shfl(l_own, base + j + 1, 64);
+            const float u = __shfl(us, base + j, 64);
+            const float bj = a.beta[j], bk = a.beta[j + 1];
+            const bool ok = swap_accept_test(u, swap_log_prob(bj, bk, car_l, lk));
+            const int ik = base + j + 1;
+            if (t == j) {
+              my_l = ok ? lk : car_l;
+              src = ok ? ik : car_i;
+              pair_acc = ok;
+            }
+            const float nl = ok ? car_l : lk;
+            const int ni = ok ? car_i : ik;
+            car_l = nl;
+            car_i = ni;
+          }
+          if (t == T - 1) {
+            my_l = car_l;
+            src = car_i;
+          }
+        } else {
+          // reference_copy: row j <- row k, row k untouched, so every pair compares
+          // the original rows j and j+1: no carried state, fully parallel.
+          const float lk = __shfl(my_l, lane + 1, 64);
+          if (t < T - 1) {
+            const bool ok = swap_accept_test(us, swap_log_prob(beta_t, a.beta[t + 1], my_l, lk));
+            if (ok) {
+              my_l = lk;
+              src = lane + 1;
+            }
+            pair_acc = ok;
+          }
+        }
+      } else {
+        // even/odd: event n attempts the disjoint pairs (j, j+1) with j == n (mod 2)
+        const int par = (ev_par0 + swap_in_call) & 1;
+        const bool lower = ((t & 1) == par);          // this lane is the lower index j of its pair
+        const int partner_t = lower ? t + 1 : t - 1;
+        const bool valid = partner_t >= 0 && partner_t < T;
+        const int partner = base + (valid ? partner_t : t);
+        const float l_other = __shfl(my_l, partner, 64);
+        const float u_low = __shfl(us, lower ? lane : partner, 64);
+        if (valid) {
+          const int tj = lower ? t : partner_t;
+          const float lj = lower ? my_l : l_other;
+          const float lk = lower ? l_other : my_l;
+          const bool ok = swap_accept_test(u_low, swap_log_prob(a.beta[tj], a.beta[tj + 1], lj, lk));
+          if (ok && (lower || a.swap_mode == PTRWM_SWAP_EXCHANGE)) {
+            my_l = l_other;
+            src = partner;
+          }
+          pair_acc = ok && lower;
+        }
+      }
+      if (pair_acc) {
+        ++n_swap_acc;
+        last_event = swap_in_call;
+      }
+      // commit MH move and swap in one pass: fetch the post-MH vector of lane `src`
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        if (d < D) {
+          const float v = acc ? y[d] : x[d];
+          const float w = __shfl(v, src, 64);
+          const float dl = sub_rn(w, x[d]);
+          j2 = fmaf(dl, dl, j2);
+          x[d] = w;
+        }
+        if ((d & 7) == 7) sched_fence();
+      }
+      lp = my_l;
+      ++swap_in_call;
+    }
+
+    if (count_on) {
+      n_acc += acc ? 1u : 0u;
+      sq += (double)j2;
+    }
+    if constexpr (FULL) {
+      if (trace_on) {
+        const long long row = ((a.full.trace_row0 + i) * a.full.trace_chains + chain) * a.full.trace_temps + t;
+        float *__restrict__ tr = a.full.trace + row * D;
+#pragma unroll
+        for (int d = 0; d < DP; ++d)
+          if (d < D) tr[d] = x[d];
+        if (a.full.trace_logp != nullptr) a.full.trace_logp[row] = lp;
+      }
+    }
+  }
+
+  if (live) {
+    float *__restrict__ xp = a.state + rep * D0;
+#pragma unroll
+    for (int d = 0; d < DP; ++d)
+      if (d < D0) xp[d] = x[d];
+    a.logp[rep] = lp;
+    if (a.n_accept != nullptr) a.n_accept[rep] += (long long)n_acc;
+    if (a.sq_jump != nullptr) a.sq_jump[rep] += sq;
+    if (a.swap_accept != nullptr) a.swap_accept[rep] += (long long)n_swap_acc;
+    if (a.last_swap_ordinal != nullptr && last_event >= 0) {
+      // 1-based attempt ordinal counted from the start of the run.  Sequential order: T-1 attempts
+      // per event; even/odd events have a varying pair count, so the event number is recorded.
+      const long long ev = a.first_swap_event + last_event;
+      const long long ord = (a.swap_order == PTRWM_ORDER_SEQUENTIAL) ? ev * (T - 1) + t + 1 : ev + 1;
+      if (ord > a.last_swap_ordinal[rep]) a.last_swap_ordinal[rep] = ord;
+    }
+  }
+}
+
+// ---- standalone log-density kernel (unit parity of the targets; initial log-density) ----
+template <class Target, int DP>
+__global__ void __launch_bounds__(kBlockThreads) ptrwm_logdensity_kernel(const float *__restrict__ x,
+                                                                          float *__restrict__ out,
+                                                                          long long n, int D, TParams tp) {
+  const long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
+  if (i >= n) return;
+  float y[DP];
+  const float *__restrict__ xp = x + i * D;
+#pragma unroll
+  for (int d = 0; d < DP; ++d) y[d] = (d < D) ? xp[d] : 0.0f;
+  out[i] = Target::logp(y, D, tp);
+}
+
+// ---- standalone proposal kernel (unit parity of the three samplers) ----
+template <class Proposal, int DP>
+__global__ void __launch_bounds__(kBlockThreads) ptrwm_propose_kernel(
+    float *__restrict__ out, long long n, int D, int T, const float *__restrict__ temp_scale, PParams pp,
+    const float *__restrict__ ext_raw, int n_raw_ext, unsigned k0, unsigned k1) {
+  const long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
+  if (i >= n * T) return;
+  const long long row = i / T;
+  const int t = (int)(i - row * T);
+  float x[DP], y[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) x[d] = 0.0f;
+  RngCtx rc;
+  rc.c0hi = (uint32_t)((unsigned long long)row >> 32) << 16;
+  rc.c1 = (uint32_t)row;  // "step" = row, chain 0
+  rc.c2 = 0;
+  rc.c3 = (uint32_t)t | (kStreamMH << 8);
+  rc.k0 = k0;
+  rc.k1 = k1;
+  const float *er = ext_raw != nullptr ? ext_raw + i * n_raw_ext : nullptr;
+  Proposal::propose(y, x, D, temp_scale[t], pp, rc, er, 0.0f);
+  float *__restrict__ op = out + i * D;
+#pragma unroll
+  for (int d = 0; d < DP; ++d)
+    if (d < D) op[d] = y[d];
+}
+
+}  // namespace ptrwm

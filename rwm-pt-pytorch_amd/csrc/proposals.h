@@ -1,0 +1,171 @@
+// Proposal increment samplers as device functors.
+//
+// Each functor fills y = x + increment for one (chain, temperature) replica and
+// returns the accept uniform.  Raw randoms come either from the replica's
+// Philox blocks for this step, or (fixture mode) from caller-provided arrays of
+// the same raw quantities the reference draws with torch.randn / torch.rand.
+//
+// Raw-word index map inside one step (stream 0), shared with the oracle:
+//   NORMAL          dims pairwise via Box-Muller on words (2p, 2p+1);
+//                   accept uniform = word 2*ceil(D/2)
+//   LAPLACE         dim d uses word d; accept uniform = word D
+//   UNIFORM_RADIUS  dims as NORMAL; radius uniform = word 2*ceil(D/2); accept = the next word
+// word w lives in Philox block w/4, lane w%4.
+#pragma once
+#include "philox.h"
+#include "../../include/ptrwm.h"
+
+namespace ptrwm {
+
+struct RngCtx {
+  uint32_t c0hi, c1, c2, c3, k0, k1;
+};
+
+struct PParams {
+  const float *__restrict__ dim_scale;  // [D] Laplace, wave-uniform
+  float inv_dim;
+};
+
+__device__ __forceinline__ uint32_t pick(const u32x4 &r, int lane4) {
+  return lane4 == 0 ? r.x : (lane4 == 1 ? r.y : (lane4 == 2 ? r.z : r.w));
+}
+
+// Fills z[0..D) with standard normals (Box-Muller pairs) and returns the Philox
+// words at raw indices `w_a` and `w_a + 1` (as [0,1) uniforms) for the caller.
+template <int DP>
+__device__ __forceinline__ void philox_normals(float (&z)[DP], int D, const RngCtx &rc, int w_a,
+                                               float &ua, float &ub) {
+  constexpr int NB = DP / 4 + 1;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    if (4 * c <= w_a + 1) {
+      const u32x4 r = philox4x32_10(rc.c0hi | (uint32_t)c, rc.c1, rc.c2, rc.c3, rc.k0, rc.k1);
+      if (4 * c < DP && 4 * c < D) {
+        float z0, z1;
+        box_muller(r.x, r.y, z0, z1);
+        z[4 * c < DP ? 4 * c : 0] = z0;
+        if (4 * c + 1 < DP && 4 * c + 1 < D) z[4 * c + 1 < DP ? 4 * c + 1 : 0] = z1;
+      }
+      if (4 * c + 2 < DP && 4 * c + 2 < D) {
+        float z0, z1;
+        box_muller(r.z, r.w, z0, z1);
+        z[4 * c + 2 < DP ? 4 * c + 2 : 0] = z0;
+        if (4 * c + 3 < DP && 4 * c + 3 < D) z[4 * c + 3 < DP ? 4 * c + 3 : 0] = z1;
+      }
+      // w_a is even by construction (2*ceil(D/2)), so it is lane 0 or 2 of its block
+      if (4 * c == w_a) {
+        ua = u01(r.x);
+        ub = u01(r.y);
+      }
+      if (4 * c + 2 == w_a) {
+        ua = u01(r.z);
+        ub = u01(r.w);
+      }
+      sched_fence();
+    }
+  }
+}
+
+// NormalProposal.sample, proposal_distributions/normal.py:33-36,46-55 (`randn * std`) and the
+// diagonal-Cholesky bmm of the PT class, algorithms/pt_rwm_gpu_optimized.py:445-455,576-592.
+template <int DP>
+struct NormalProposal {
+  static constexpr int kKind = PTRWM_PROPOSAL_NORMAL;
+  __device__ __forceinline__ static float propose(float (&y)[DP], const float (&x)[DP], int D,
+                                                  float tscale, const PParams &, const RngCtx &rc,
+                                                  const float *ext_raw, float ext_u) {
+    float u_acc = ext_u;
+    if (ext_raw != nullptr) {
+#pragma unroll
+      for (int d = 0; d < DP; ++d)
+        if (d < D) y[d] = add_rn(x[d], mul_rn(ext_raw[d], tscale));
+    } else {
+      float ub;
+      philox_normals<DP>(y, D, rc, 2 * ((D + 1) >> 1), u_acc, ub);
+#pragma unroll
+      for (int d = 0; d < DP; ++d)
+        if (d < D) y[d] = add_rn(x[d], mul_rn(y[d], tscale));
+    }
+    return u_acc;
+  }
+};
+
+// LaplaceProposal.sample, proposal_distributions/laplace.py:24-37,46-69:
+//   u = rand - 0.5;  x = -scale * sign(u) * log1p(clamp(-2|u|, min=-0.999999))
+template <int DP>
+struct LaplaceProposal {
+  static constexpr int kKind = PTRWM_PROPOSAL_LAPLACE;
+  __device__ __forceinline__ static float transform(float u01v, float scale) {
+    const float u = u01v - 0.5f;
+    const float au = __builtin_fabsf(u);
+    const float arg = __builtin_fmaxf(-2.0f * au, -0.999999f);
+    const float l1p = hw_log2(1.0f + arg) * kLn2;
+    const float sgn = (u > 0.0f) ? 1.0f : ((u < 0.0f) ? -1.0f : 0.0f);
+    return mul_rn(mul_rn(-scale, sgn), l1p);
+  }
+  __device__ __forceinline__ static float propose(float (&y)[DP], const float (&x)[DP], int D,
+                                                  float tscale, const PParams &pp, const RngCtx &rc,
+                                                  const float *ext_raw, float ext_u) {
+    float u_acc = ext_u;
+    if (ext_raw != nullptr) {
+#pragma unroll
+      for (int d = 0; d < DP; ++d)
+        if (d < D) y[d] = add_rn(x[d], transform(ext_raw[d], mul_rn(pp.dim_scale[d], tscale)));
+    } else {
+      constexpr int NB = DP / 4 + 1;
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        if (4 * c <= D) {
+          const u32x4 r = philox4x32_10(rc.c0hi | (uint32_t)c, rc.c1, rc.c2, rc.c3, rc.k0, rc.k1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int d = 4 * c + q;
+            if (d < DP && d < D) {
+              const int ds = d < DP ? d : 0;
+              y[ds] = add_rn(x[ds], transform(u01(pick(r, q)), mul_rn(pp.dim_scale[ds], tscale)));
+            }
+            if (d == D) u_acc = u01(pick(r, q));
+          }
+          sched_fence();
+        }
+      }
+    }
+    return u_acc;
+  }
+};
+
+// UniformRadiusProposal.sample, proposal_distributions/uniform.py:27-37,47-73:
+//   g = randn(D); n = |g| (1 if <= 1e-12); r = R_eff * U^(1/D); inc = g / n * r
+template <int DP>
+struct UniformRadiusProposal {
+  static constexpr int kKind = PTRWM_PROPOSAL_UNIFORM_RADIUS;
+  __device__ __forceinline__ static float propose(float (&y)[DP], const float (&x)[DP], int D,
+                                                  float tscale, const PParams &pp, const RngCtx &rc,
+                                                  const float *ext_raw, float ext_u) {
+    float u_acc = ext_u, u_rad;
+    if (ext_raw != nullptr) {
+#pragma unroll
+      for (int d = 0; d < DP; ++d)
+        if (d < D) y[d] = ext_raw[d];
+      u_rad = ext_raw[D];
+    } else {
+      float ua = 0.0f, ub = 0.0f;
+      philox_normals<DP>(y, D, rc, 2 * ((D + 1) >> 1), ua, ub);
+      u_rad = ua;
+      u_acc = ub;
+    }
+    float n2 = 0.0f;
+#pragma unroll
+    for (int d = 0; d < DP; ++d)
+      if (d < D) n2 = fmaf(y[d], y[d], n2);
+    const float nrm = hw_sqrt(n2);
+    const float safe = nrm > 1e-12f ? nrm : 1.0f;
+    const float rad = tscale * hw_exp2(pp.inv_dim * hw_log2(u_rad));
+#pragma unroll
+    for (int d = 0; d < DP; ++d)
+      if (d < D) y[d] = add_rn(x[d], mul_rn(div_rn(y[d], safe), rad));
+    return u_acc;
+  }
+};
+
+}  // namespace ptrwm

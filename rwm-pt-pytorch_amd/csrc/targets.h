@@ -1,0 +1,222 @@
+// Target log-densities as device functors over a register-resident dim-vector.
+//
+// Each functor restates, in fp32, the `log_density` of one reference class
+// (citations per functor).  `y` is the proposal held in VGPRs (DP = compiled
+// register width >= dim); every loop is fully unrolled so all indexing is static
+// and the per-dimension parameter vectors are wave-uniform scalar loads.
+#pragma once
+#include "philox.h"
+#include "../../include/ptrwm.h"
+
+namespace ptrwm {
+
+struct TParams {
+  float p[12];
+  int ip[4];
+  const float *__restrict__ vec0;
+  const float *__restrict__ vec1;
+  unsigned long long mask[2];  // HybridRosenbrock: bit i set => coordinate i starts a block
+};
+
+constexpr float kNegInf = -__builtin_huge_valf();
+
+// RoughCarpetDistributionTorch.log_density, target_distributions/multimodal_torch.py:470-510:
+//   sum_d logsumexp_k( -0.5 (s_d x_d - m_k)^2 - log sqrt(2 pi) + log w_k ) + sum_d log s_d.
+// Per dimension: the three exponents are formed directly from (x - m_k) (no
+// expansion of the square, which would cancel catastrophically at the +-15
+// modes), sorted with max3/med3/min3 so only two v_exp_f32 are needed, and the
+// log of the 3-term sum is deferred: sum_d log2(s_d) = log2(prod_d s_d) with
+// s_d in [1,3], one v_log_f32 per 32 dimensions instead of one per dimension.
+template <int DP>
+struct RoughCarpet {
+  static constexpr int kKind = PTRWM_TARGET_ROUGH_CARPET;
+  template <bool SCALED>
+  __device__ __forceinline__ static float logp_impl(const float (&y)[DP], int D, const TParams &tp) {
+    const float m0 = tp.p[0], m1 = tp.p[1], m2 = tp.p[2];
+    // log2-domain log-weights
+    const float w0 = tp.p[3] * kLog2e, w1 = tp.p[4] * kLog2e, w2 = tp.p[5] * kLog2e;
+    const float nh = -0.5f * kLog2e;
+    float sum_mx = 0.0f, prod = 1.0f, lg = 0.0f;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      if (d < D) {
+        float xs = y[d];
+        if constexpr (SCALED) xs *= tp.vec0[d];
+        const float d0 = xs - m0, d1 = xs - m1, d2 = xs - m2;
+        const float a0 = fmaf(d0 * d0, nh, w0);
+        const float a1 = fmaf(d1 * d1, nh, w1);
+        const float a2 = fmaf(d2 * d2, nh, w2);
+        const float mx = __builtin_fmaxf(__builtin_fmaxf(a0, a1), a2);
+        const float mn = __builtin_fminf(__builtin_fminf(a0, a1), a2);
+        const float md = __builtin_amdgcn_fmed3f(a0, a1, a2);
+        const float s = 1.0f + hw_exp2(md - mx) + hw_exp2(mn - mx);
+        sum_mx += mx;
+        prod *= s;
+      }
+      if ((d & 3) == 3) sched_fence();
+      if ((d & 31) == 31 && d + 1 < DP) {
+        lg += hw_log2(prod);
+        prod = 1.0f;
+      }
+    }
+    lg += hw_log2(prod);
+    // p[6] = log_jacobian, p[7] = -dim * log(sqrt(2 pi)) folded on the host
+    return fmaf(sum_mx + lg, kLn2, tp.p[7]) + tp.p[6];
+  }
+  __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+    // one wave-uniform branch per evaluation instead of one per dimension
+    return tp.vec0 != nullptr ? logp_impl<true>(y, D, tp) : logp_impl<false>(y, D, tp);
+  }
+};
+
+// ThreeMixtureDistributionTorch.log_density, multimodal_torch.py:173-242.  cov_invs
+// is always the identity (:87-98) so the [B,D]x[D,D] matmul at :234 is skipped.
+//   logsumexp_k( -0.5 |s*x - mu_k|^2 + c_k ),  c_k = log_norm_const_k + log w_k (+ log_jacobian)
+template <int DP>
+struct ThreeMixture {
+  static constexpr int kKind = PTRWM_TARGET_THREE_MIXTURE;
+  template <bool SCALED>
+  __device__ __forceinline__ static float logp_impl(const float (&y)[DP], int D, const TParams &tp) {
+    float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      if (d < D) {
+        float xs = y[d];
+        if constexpr (SCALED) xs *= tp.vec1[d];
+        const float e0 = xs - tp.vec0[d];
+        const float e1 = xs - tp.vec0[D + d];
+        const float e2 = xs - tp.vec0[2 * D + d];
+        q0 = fmaf(e0, e0, q0);
+        q1 = fmaf(e1, e1, q1);
+        q2 = fmaf(e2, e2, q2);
+      }
+      if ((d & 7) == 7) sched_fence();
+    }
+    const float a0 = fmaf(-0.5f, q0, tp.p[0]);
+    const float a1 = fmaf(-0.5f, q1, tp.p[1]);
+    const float a2 = fmaf(-0.5f, q2, tp.p[2]);
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(a0, a1), a2);
+    const float s = hw_exp((a0 - mx)) + hw_exp((a1 - mx)) + hw_exp((a2 - mx));
+    return mx + hw_ln(s);
+  }
+  __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+    return tp.vec1 != nullptr ? logp_impl<true>(y, D, tp) : logp_impl<false>(y, D, tp);
+  }
+};
+
+// FullRosenbrockTorch.log_density, rosenbrock_torch.py:67-84:
+//   -sum_{i<D-1} [ b (x_{i+1} - x_i^2)^2 + a (x_i - mu_i)^2 ]
+template <int DP>
+struct FullRosenbrock {
+  static constexpr int kKind = PTRWM_TARGET_FULL_ROSENBROCK;
+  __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+    const float a = tp.p[0], b = tp.p[1];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i + 1 < DP; ++i) {
+      if (i + 1 < D) {
+        const float r = y[i + 1] - y[i] * y[i];
+        const float c = y[i] - tp.vec0[i];
+        s1 = fmaf(b * r, r, s1);
+        s2 = fmaf(a * c, c, s2);
+      }
+      if ((i & 7) == 7) sched_fence();
+    }
+    return -(s1 + s2);
+  }
+};
+
+// EvenRosenbrockTorch.log_density, rosenbrock_torch.py:194-210:
+//   -sum_{i<D/2} [ a (x_{2i} - mu_i)^2 + b (x_{2i+1} - x_{2i}^2)^2 ]
+template <int DP>
+struct EvenRosenbrock {
+  static constexpr int kKind = PTRWM_TARGET_EVEN_ROSENBROCK;
+  __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+    const float a = tp.p[0], b = tp.p[1];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int i = 0; 2 * i + 1 < DP; ++i) {
+      if (2 * i + 1 < D) {
+        const float c = y[2 * i] - tp.vec0[i];
+        const float r = y[2 * i + 1] - y[2 * i] * y[2 * i];
+        s1 = fmaf(a * c, c, s1);
+        s2 = fmaf(b * r, r, s2);
+      }
+      if ((i & 3) == 3) sched_fence();
+    }
+    return -(s1 + s2);
+  }
+};
+
+// HybridRosenbrockTorch.log_density, rosenbrock_torch.py:312-351:
+//   -a (x_0 - mu)^2 - b sum_j (x_{j,2} - x_0^2)^2 - b sum_j sum_{i>=3} (x_{j,i} - x_{j,i-1}^2)^2
+// with x_{j,i} stored flat after x_0 in blocks of n1-1.  `mask` bit i marks the
+// first coordinate of a block (its parent is x_0, otherwise the parent is x_{i-1}).
+template <int DP>
+struct HybridRosenbrock {
+  static constexpr int kKind = PTRWM_TARGET_HYBRID_ROSENBROCK;
+  __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+    const float a = tp.p[0], b = tp.p[1], mu = tp.p[2];
+    const float c0 = y[0] - mu;
+    float acc = a * c0 * c0;
+#pragma unroll
+    for (int i = 1; i < DP; ++i) {
+      if (i < D) {
+        const bool head = (tp.mask[i >> 6] >> (i & 63)) & 1ull;
+        const float parent = head ? y[0] : y[i - 1];
+        const float r = y[i] - parent * parent;
+        acc = fmaf(b * r, r, acc);
+      }
+      if ((i & 7) == 7) sched_fence();
+    }
+    return -acc;
+  }
+};
+
+// IIDGammaTorch.log_density, iid_product_torch.py:52-91:
+//   sum_d [ (k-1) log x_d - x_d / theta ] - dim (lgamma k + k log theta);  -inf if any x_d <= 0
+template <int DP>
+struct IIDGamma {
+  static constexpr int kKind = PTRWM_TARGET_IID_GAMMA;
+  __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+    const float km1 = (tp.p[0] - 1.0f) * kLn2;
+    const float inv_theta = 1.0f / tp.p[1];
+    float acc = 0.0f;
+    bool bad = false;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      if (d < D) {
+        const float v = y[d];
+        bad = bad || (v <= 0.0f);
+        acc += fmaf(km1, hw_log2(v), -(v * inv_theta));
+      }
+      if ((d & 7) == 7) sched_fence();
+    }
+    return bad ? kNegInf : acc - tp.p[2];
+  }
+};
+
+// IIDBetaTorch.log_density, iid_product_torch.py:188-229:
+//   sum_d [ (alpha-1) log x_d + (beta-1) log(1-x_d) ] + dim log(1/B(alpha,beta));  -inf outside (0,1)
+template <int DP>
+struct IIDBeta {
+  static constexpr int kKind = PTRWM_TARGET_IID_BETA;
+  __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+    const float am1 = (tp.p[0] - 1.0f) * kLn2;
+    const float bm1 = (tp.p[1] - 1.0f) * kLn2;
+    float acc = 0.0f;
+    bool bad = false;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      if (d < D) {
+        const float v = y[d];
+        bad = bad || (v <= 0.0f) || (v >= 1.0f);
+        acc += fmaf(am1, hw_log2(v), bm1 * hw_log2(1.0f - v));
+      }
+      if ((d & 7) == 7) sched_fence();
+    }
+    return bad ? kNegInf : acc + tp.p[2];
+  }
+};
+
+}  // namespace ptrwm

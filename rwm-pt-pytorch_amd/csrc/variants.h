@@ -1,0 +1,91 @@
+// Compiled-variant registry: (target, proposal, register width DP).
+//
+// dim is a run-time (wave-uniform) value; DP is the compile-time width of the
+// per-thread register arrays, the smallest entry of kDP that is >= dim.
+#pragma once
+#include "kernel.h"
+
+namespace ptrwm {
+
+// Exact widths: dims the reference's experiments actually run (data/*dim{2,3,4,5,10,20,30,50,100}*),
+// compiled with dim as a constant.  Generic widths serve every other dim <= 104 with run-time
+// predicates.  X(width, exact)
+#define PTRWM_WIDTHS(X) \
+  X(2, true) X(3, true) X(4, true) X(5, true) X(10, true) X(20, true) X(30, true) X(50, true) X(100, true) \
+  X(8, false) X(16, false) X(32, false) X(64, false) X(104, false)
+
+struct WidthInfo {
+  int dp;
+  bool exact;
+};
+#define PTRWM_X_INFO(W, E) {W, E},
+constexpr WidthInfo kWidths[] = {PTRWM_WIDTHS(PTRWM_X_INFO)};
+#undef PTRWM_X_INFO
+constexpr int kNumWidths = (int)(sizeof(kWidths) / sizeof(kWidths[0]));
+
+// exact width if one matches, else the narrowest generic width >= dim; -1 if none
+inline int width_index_for_dim(int dim) {
+  int best = -1;
+  for (int i = 0; i < kNumWidths; ++i) {
+    if (kWidths[i].exact) {
+      if (kWidths[i].dp == dim) return i;
+    } else if (kWidths[i].dp >= dim && (best < 0 || kWidths[i].dp < kWidths[best].dp)) {
+      best = i;
+    }
+  }
+  return best;
+}
+
+using RunLaunchFn = hipError_t (*)(const KArgs &, unsigned grid, bool full, hipStream_t);
+using LogpLaunchFn = hipError_t (*)(const float *, float *, long long, int, const TParams &, hipStream_t);
+
+struct TargetVariants {
+  RunLaunchFn run[PTRWM_PROPOSAL_COUNT][kNumWidths];
+  LogpLaunchFn logp[kNumWidths];
+};
+
+template <class Target, class Proposal, int DP, bool EXACT>
+hipError_t launch_run(const KArgs &a, unsigned grid, bool full, hipStream_t stream) {
+  if (full)
+    hipLaunchKernelGGL((ptrwm_step_kernel<Target, Proposal, DP, EXACT, true>), dim3(grid), dim3(kBlockThreads), 0,
+                       stream, a);
+  else
+    hipLaunchKernelGGL((ptrwm_step_kernel<Target, Proposal, DP, EXACT, false>), dim3(grid), dim3(kBlockThreads), 0,
+                       stream, a);
+  return hipGetLastError();
+}
+
+template <class Target, int DP>
+hipError_t launch_logp(const float *x, float *out, long long n, int D, const TParams &tp, hipStream_t stream) {
+  const unsigned grid = (unsigned)((n + kBlockThreads - 1) / kBlockThreads);
+  hipLaunchKernelGGL((ptrwm_logdensity_kernel<Target, DP>), dim3(grid), dim3(kBlockThreads), 0, stream, x, out,
+                     n, D, tp);
+  return hipGetLastError();
+}
+
+// One translation unit per target (compiled in parallel) defines its table with this macro.
+// The table lives inside a host function so the device pass does not try to emit it.
+#define PTRWM_X_RUN_N(W, E) launch_run<TGT<W>, NormalProposal<W>, W, E>,
+#define PTRWM_X_RUN_L(W, E) launch_run<TGT<W>, LaplaceProposal<W>, W, E>,
+#define PTRWM_X_RUN_U(W, E) launch_run<TGT<W>, UniformRadiusProposal<W>, W, E>,
+#define PTRWM_X_LOGP(W, E) launch_logp<TGT<W>, W>,
+#define PTRWM_DEFINE_TARGET_VARIANTS(SYMBOL, TARGET)                                   \
+  template <int W>                                                                     \
+  using TGT = TARGET<W>;                                                               \
+  const TargetVariants &SYMBOL() {                                                     \
+    static const TargetVariants v = {{{PTRWM_WIDTHS(PTRWM_X_RUN_N)},                   \
+                                      {PTRWM_WIDTHS(PTRWM_X_RUN_L)},                   \
+                                      {PTRWM_WIDTHS(PTRWM_X_RUN_U)}},                  \
+                                     {PTRWM_WIDTHS(PTRWM_X_LOGP)}};                    \
+    return v;                                                                          \
+  }
+
+const TargetVariants &rough_carpet_variants();
+const TargetVariants &three_mixture_variants();
+const TargetVariants &full_rosenbrock_variants();
+const TargetVariants &even_rosenbrock_variants();
+const TargetVariants &hybrid_rosenbrock_variants();
+const TargetVariants &iid_gamma_variants();
+const TargetVariants &iid_beta_variants();
+
+}  // namespace ptrwm

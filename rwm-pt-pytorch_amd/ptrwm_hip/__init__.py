@@ -1,0 +1,357 @@
+"""ctypes binding of the C-ABI engine library (include/ptrwm.h -> lib/libptrwm_hip.so).
+
+This is the only place Python touches the HIP engine.  torch is used for device memory and streams
+only: every call passes raw ``tensor.data_ptr()`` device pointers and the current HIP stream.
+
+There is no CPU or eager-torch fallback: if the library is missing, or a tensor is not on a ROCm
+device, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import torch  # noqa: F401  (must be imported first: loads the HIP runtime the library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libptrwm_hip.so")
+
+ABI_VERSION = 1
+MAX_DIM = 104
+MAX_TEMPS = 64
+
+# target kinds (include/ptrwm.h)
+TARGET_ROUGH_CARPET = 0
+TARGET_THREE_MIXTURE = 1
+TARGET_FULL_ROSENBROCK = 2
+TARGET_EVEN_ROSENBROCK = 3
+TARGET_HYBRID_ROSENBROCK = 4
+TARGET_IID_GAMMA = 5
+TARGET_IID_BETA = 6
+# proposal kinds
+PROPOSAL_NORMAL = 0
+PROPOSAL_LAPLACE = 1
+PROPOSAL_UNIFORM_RADIUS = 2
+# swap semantics
+SWAP_EXCHANGE = 0
+SWAP_REFERENCE_COPY = 1
+ORDER_SEQUENTIAL = 0
+ORDER_EVEN_ODD = 1
+
+SWAP_MODES = {"exchange": SWAP_EXCHANGE, "reference_copy": SWAP_REFERENCE_COPY}
+SWAP_ORDERS = {"sequential": ORDER_SEQUENTIAL, "even_odd": ORDER_EVEN_ODD}
+
+
+class PTRWMError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+    def __init__(self, code: int, where: str):
+        self.code = code
+        super().__init__(f"{where}: {strerror(code)} (status {code})")
+
+
+class TargetDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("dim", C.c_int32),
+        ("p", C.c_float * 12),
+        ("ip", C.c_int32 * 4),
+        ("vec0", C.c_void_p),
+        ("vec1", C.c_void_p),
+    ]
+
+
+class ProposalDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("inv_dim", C.c_float),
+        ("temp_scale", C.c_void_p),
+        ("dim_scale", C.c_void_p),
+    ]
+
+
+class RunArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("n_temps", C.c_int32),
+        ("n_chains", C.c_int64),
+        ("chain_offset", C.c_int64),
+        ("state", C.c_void_p),
+        ("logp", C.c_void_p),
+        ("beta", C.c_void_p),
+        ("n_accept", C.c_void_p),
+        ("sq_jump", C.c_void_p),
+        ("swap_accept", C.c_void_p),
+        ("last_swap_ordinal", C.c_void_p),
+        ("step0", C.c_int64),
+        ("n_steps", C.c_int64),
+        ("burn_in", C.c_int64),
+        ("swap_every", C.c_int32),
+        ("swap_mode", C.c_int32),
+        ("swap_order", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("seed", C.c_uint64),
+        ("ext_prop", C.c_void_p),
+        ("ext_u", C.c_void_p),
+        ("ext_swap_u", C.c_void_p),
+        ("trace", C.c_void_p),
+        ("trace_logp", C.c_void_p),
+        ("trace_chains", C.c_int64),
+        ("trace_temps", C.c_int32),
+        ("reserved1", C.c_int32),
+        ("trace_row0", C.c_int64),
+        ("accept_flags", C.c_void_p),
+    ]
+
+
+# every symbol include/ptrwm.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "ptrwm_abi_version": (C.c_int32, []),
+    "ptrwm_strerror": (C.c_char_p, [C.c_int32]),
+    "ptrwm_ext_raw_per_step": (C.c_int32, [C.c_int32, C.c_int32]),
+    "ptrwm_has_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    "ptrwm_run": (C.c_int32, [C.POINTER(TargetDesc), C.POINTER(ProposalDesc), C.POINTER(RunArgs), C.c_void_p]),
+    "ptrwm_logdensity": (C.c_int32, [C.POINTER(TargetDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ptrwm_propose": (
+        C.c_int32,
+        [C.POINTER(ProposalDesc), C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p],
+    ),
+    "ptrwm_philox_raw": (
+        C.c_int32,
+        [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int64, C.c_void_p, C.c_void_p],
+    ),
+}
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """Load (once) and type the engine library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"HIP engine library not found at {p}. Build it first: "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C rwm-pt-pytorch_amd/csrc`. "
+            "There is no CPU fallback."
+        )
+    lib = C.CDLL(p)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.ptrwm_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"ABI mismatch: library {lib.ptrwm_abi_version()} vs binding {ABI_VERSION}")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def strerror(code: int) -> str:
+    return load_library().ptrwm_strerror(code).decode()
+
+
+def _require_device(t: torch.Tensor, name: str, dtype: torch.dtype) -> int:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: the PT-RWM engine only runs on a ROCm GPU (no CPU fallback)."
+        )
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def _opt(t: Optional[torch.Tensor], name: str, dtype: torch.dtype) -> Optional[int]:
+    return None if t is None else _require_device(t, name, dtype)
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+@dataclass
+class Target:
+    """Host-side description of a target density; tensors are kept alive by the owner."""
+
+    kind: int
+    dim: int
+    p: tuple = ()
+    ip: tuple = ()
+    vec0: Optional[torch.Tensor] = None
+    vec1: Optional[torch.Tensor] = None
+
+    def desc(self) -> TargetDesc:
+        d = TargetDesc()
+        d.kind = self.kind
+        d.dim = self.dim
+        for i, v in enumerate(self.p):
+            d.p[i] = float(v)
+        for i, v in enumerate(self.ip):
+            d.ip[i] = int(v)
+        d.vec0 = _opt(self.vec0, "target.vec0", torch.float32)
+        d.vec1 = _opt(self.vec1, "target.vec1", torch.float32)
+        return d
+
+
+@dataclass
+class Proposal:
+    kind: int
+    temp_scale: torch.Tensor  # [T] float32 device
+    dim_scale: Optional[torch.Tensor] = None  # [D] float32 device (Laplace)
+    inv_dim: float = 0.0
+
+    def desc(self) -> ProposalDesc:
+        d = ProposalDesc()
+        d.kind = self.kind
+        d.inv_dim = float(self.inv_dim)
+        d.temp_scale = _require_device(self.temp_scale, "proposal.temp_scale", torch.float32)
+        d.dim_scale = _opt(self.dim_scale, "proposal.dim_scale", torch.float32)
+        return d
+
+
+def ext_raw_per_step(proposal_kind: int, dim: int) -> int:
+    n = load_library().ptrwm_ext_raw_per_step(proposal_kind, dim)
+    if n < 0:
+        raise PTRWMError(n, "ptrwm_ext_raw_per_step")
+    return n
+
+
+def has_variant(target_kind: int, proposal_kind: int, dim: int) -> bool:
+    return bool(load_library().ptrwm_has_variant(target_kind, proposal_kind, dim))
+
+
+def logdensity(target: Target, x: torch.Tensor) -> torch.Tensor:
+    """log-density of every row of ``x`` ([n, dim] float32 on the GPU) -> [n] float32."""
+    lib = load_library()
+    if x.dim() != 2 or x.shape[1] != target.dim:
+        raise ValueError(f"x must have shape [n, {target.dim}], got {tuple(x.shape)}")
+    xp = _require_device(x, "x", torch.float32)
+    out = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+    desc = target.desc()
+    rc = lib.ptrwm_logdensity(C.byref(desc), xp, out.data_ptr(), x.shape[0], _stream(x.device))
+    if rc != 0:
+        raise PTRWMError(rc, "ptrwm_logdensity")
+    return out
+
+
+def propose(proposal: Proposal, dim: int, n: int, seed: int = 0, ext_raw: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Proposal increments [n, T, dim] from Philox(seed) or from external raw randoms [n, T, raw]."""
+    lib = load_library()
+    T = proposal.temp_scale.numel()
+    dev = proposal.temp_scale.device
+    desc = proposal.desc()
+    if ext_raw is not None:
+        if tuple(ext_raw.shape) != (n, T, ext_raw_per_step(proposal.kind, dim)):
+            raise ValueError(f"ext_raw has shape {tuple(ext_raw.shape)}")
+    out = torch.empty(n, T, dim, device=dev, dtype=torch.float32)
+    rc = lib.ptrwm_propose(
+        C.byref(desc), dim, T, n, _opt(ext_raw, "ext_raw", torch.float32), seed & (2**64 - 1), out.data_ptr(), _stream(dev)
+    )
+    if rc != 0:
+        raise PTRWMError(rc, "ptrwm_propose")
+    return out
+
+
+def philox_raw(seed: int, c0: int, c1: int, c2: int, c3: int, n: int, device) -> torch.Tensor:
+    """n consecutive Philox4x32-10 blocks (counter c0+i) as an int64 tensor [n, 4] of uint32 values."""
+    lib = load_library()
+    out = torch.empty(n, 4, device=device, dtype=torch.int32)
+    if not out.is_cuda:
+        raise RuntimeError("philox_raw needs a ROCm device")
+    rc = lib.ptrwm_philox_raw(seed, c0, c1, c2, c3, n, out.data_ptr(), _stream(out.device))
+    if rc != 0:
+        raise PTRWMError(rc, "ptrwm_philox_raw")
+    return out.to(torch.int64) & 0xFFFFFFFF
+
+
+def run(
+    target: Target,
+    proposal: Proposal,
+    *,
+    state: torch.Tensor,  # [C, T, D] float32
+    logp: torch.Tensor,  # [C, T] float32
+    beta: torch.Tensor,  # [T] float32
+    step0: int,
+    n_steps: int,
+    burn_in: int = 0,
+    swap_every: int = 1,
+    swap_mode: int = SWAP_EXCHANGE,
+    swap_order: int = ORDER_SEQUENTIAL,
+    seed: int = 0,
+    chain_offset: int = 0,
+    n_accept: Optional[torch.Tensor] = None,  # [C, T] int64
+    sq_jump: Optional[torch.Tensor] = None,  # [C, T] float64
+    swap_accept: Optional[torch.Tensor] = None,  # [C, T] int64
+    last_swap_ordinal: Optional[torch.Tensor] = None,  # [C, T] int64
+    ext_prop: Optional[torch.Tensor] = None,
+    ext_u: Optional[torch.Tensor] = None,
+    ext_swap_u: Optional[torch.Tensor] = None,
+    trace: Optional[torch.Tensor] = None,  # [rows, trace_chains, trace_temps, D]
+    trace_logp: Optional[torch.Tensor] = None,
+    trace_row0: int = 0,
+    accept_flags: Optional[torch.Tensor] = None,  # [n_steps, C, T] uint8
+) -> None:
+    """Enqueue ``n_steps`` fused MH(+swap) steps for every (chain, temperature) replica."""
+    lib = load_library()
+    if state.dim() != 3:
+        raise ValueError("state must be [n_chains, n_temps, dim]")
+    Cn, T, D = state.shape
+    if D != target.dim:
+        raise ValueError(f"state dim {D} != target dim {target.dim}")
+    if tuple(logp.shape) != (Cn, T) or beta.numel() != T or proposal.temp_scale.numel() != T:
+        raise ValueError("logp/beta/temp_scale shapes do not match state")
+    a = RunArgs()
+    a.struct_size = C.sizeof(RunArgs)
+    a.n_temps = T
+    a.n_chains = Cn
+    a.chain_offset = chain_offset
+    a.state = _require_device(state, "state", torch.float32)
+    a.logp = _require_device(logp, "logp", torch.float32)
+    a.beta = _require_device(beta, "beta", torch.float32)
+    for name, t, dt in (
+        ("n_accept", n_accept, torch.int64),
+        ("sq_jump", sq_jump, torch.float64),
+        ("swap_accept", swap_accept, torch.int64),
+        ("last_swap_ordinal", last_swap_ordinal, torch.int64),
+    ):
+        if t is not None and tuple(t.shape) != (Cn, T):
+            raise ValueError(f"{name} must have shape [{Cn}, {T}]")
+        setattr(a, name, _opt(t, name, dt))
+    a.step0 = step0
+    a.n_steps = n_steps
+    a.burn_in = burn_in
+    a.swap_every = swap_every
+    a.swap_mode = swap_mode
+    a.swap_order = swap_order
+    a.seed = seed & (2**64 - 1)
+    a.ext_prop = _opt(ext_prop, "ext_prop", torch.float32)
+    a.ext_u = _opt(ext_u, "ext_u", torch.float32)
+    a.ext_swap_u = _opt(ext_swap_u, "ext_swap_u", torch.float32)
+    if ext_prop is not None:
+        raw = ext_raw_per_step(proposal.kind, D)
+        if tuple(ext_prop.shape) != (n_steps, Cn, T, raw) or ext_u is None or tuple(ext_u.shape) != (n_steps, Cn, T):
+            raise ValueError("ext_prop/ext_u shapes do not match [n_steps, n_chains, n_temps, raw]")
+    a.trace = _opt(trace, "trace", torch.float32)
+    a.trace_logp = _opt(trace_logp, "trace_logp", torch.float32)
+    if trace is not None:
+        if trace.dim() != 4 or trace.shape[3] != D or trace.shape[0] < trace_row0 + n_steps:
+            raise ValueError("trace must be [rows >= trace_row0 + n_steps, trace_chains, trace_temps, dim]")
+        a.trace_chains = trace.shape[1]
+        a.trace_temps = trace.shape[2]
+    a.trace_row0 = trace_row0
+    if accept_flags is not None and tuple(accept_flags.shape) != (n_steps, Cn, T):
+        raise ValueError("accept_flags must be [n_steps, n_chains, n_temps]")
+    a.accept_flags = _opt(accept_flags, "accept_flags", torch.uint8)
+    tdesc = target.desc()
+    pdesc = proposal.desc()
+    rc = lib.ptrwm_run(C.byref(tdesc), C.byref(pdesc), C.byref(a), _stream(state.device))
+    if rc != 0:
+        raise PTRWMError(rc, "ptrwm_run")
