@@ -1,0 +1,126 @@
+"""Device-side state of a sampler run and the calls into the fused HIP kernel.
+
+Shared by `RandomWalkMH_GPU_Optimized` (one temperature) and `ParallelTemperingRWM_GPU_Optimized`
+(a ladder).  Layout in HBM (all contiguous, row-major):
+
+    state        float32 [n_replicas, n_temps, dim]   the replicas' current points
+    logp         float32 [n_replicas, n_temps]        their log-densities
+    n_accept     int64   [n_replicas, n_temps]        MH acceptances after burn-in
+    sq_jump      float64 [n_replicas, n_temps]        sum of squared jump distances after burn-in
+    swap_accept  int64   [n_replicas, n_temps]        accepted swaps of pair (t, t+1)
+    last_ord     int64   [n_replicas, n_temps]        attempt ordinal of the pair's last accepted swap
+
+`n_replicas` is the axis the reference does not have: independent copies of the whole chain /
+ladder, one Philox subsequence each (global replica id = chain_offset + local index), so a run is
+invariant to how replicas are sharded over GPUs.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+import ptrwm_hip
+
+
+def resolve_device(device) -> torch.device:
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    return torch.device(device)
+
+
+def draw_seed() -> int:
+    """A Philox key from torch's global CPU generator: `torch.manual_seed(s)` (which the harness calls
+    after constructing the sampler, interfaces/simulation_gpu.py) therefore fixes the whole run."""
+    return int(torch.randint(0, 2**62, (1,)).item())
+
+
+class EngineRun:
+    def __init__(self, *, target_dist, proposal: "ptrwm_hip.Proposal", beta_ladder: Sequence[float], dim: int,
+                 device: torch.device, n_replicas: int, initial_state: np.ndarray, burn_in: int, swap_every: int,
+                 swap_mode: str, swap_order: str, seed: Optional[int], chain_offset: int = 0):
+        if swap_mode not in ptrwm_hip.SWAP_MODES:
+            raise ValueError(f"swap_mode must be one of {sorted(ptrwm_hip.SWAP_MODES)}, got {swap_mode!r}")
+        if swap_order not in ptrwm_hip.SWAP_ORDERS:
+            raise ValueError(f"swap_order must be one of {sorted(ptrwm_hip.SWAP_ORDERS)}, got {swap_order!r}")
+        if n_replicas < 1:
+            raise ValueError("number of replicas must be >= 1")
+        n_temps = len(beta_ladder)
+        if not 1 <= n_temps <= ptrwm_hip.MAX_TEMPS:
+            raise ValueError(f"the fused kernel keeps one ladder in one wavefront: 1..{ptrwm_hip.MAX_TEMPS} "
+                             f"temperatures, got {n_temps}")
+        if not 1 <= dim <= ptrwm_hip.MAX_DIM:
+            raise ValueError(f"dim must be in 1..{ptrwm_hip.MAX_DIM} for the fused kernel, got {dim}")
+        if device.type != "cuda":
+            raise RuntimeError(
+                "The PT-RWM engine runs only on a ROCm GPU (device='cuda'); there is no CPU fallback. "
+                f"Requested device: {device}"
+            )
+        self.target = target_dist.engine_target()
+        self.proposal = proposal
+        self.dim, self.n_temps, self.n_replicas = dim, n_temps, n_replicas
+        self.device = device
+        self.burn_in, self.swap_every = int(burn_in), int(swap_every)
+        self.swap_mode = ptrwm_hip.SWAP_MODES[swap_mode]
+        self.swap_order = ptrwm_hip.SWAP_ORDERS[swap_order]
+        self.seed = draw_seed() if seed is None else int(seed)
+        self.chain_offset = int(chain_offset)
+        self.steps_done = 0
+        self.beta = torch.tensor(list(beta_ladder), device=device, dtype=torch.float32)
+        x0 = torch.as_tensor(np.asarray(initial_state), dtype=torch.float32).to(device)
+        # every temperature (and replica) starts from the same point (pt_rwm_gpu_optimized.py:478-484)
+        self.state = x0.expand(n_replicas, n_temps, dim).contiguous()
+        self.logp = ptrwm_hip.logdensity(self.target, self.state.view(-1, dim)).view(n_replicas, n_temps).contiguous()
+        shape = (n_replicas, n_temps)
+        self.n_accept = torch.zeros(shape, device=device, dtype=torch.int64)
+        self.sq_jump = torch.zeros(shape, device=device, dtype=torch.float64)
+        self.swap_accept = torch.zeros(shape, device=device, dtype=torch.int64)
+        self.last_ord = torch.zeros(shape, device=device, dtype=torch.int64)
+
+    # ---- stepping ---------------------------------------------------------------------------
+    def advance(self, n_steps: int, trace: Optional[torch.Tensor] = None, trace_logp: Optional[torch.Tensor] = None,
+                trace_row0: int = 0) -> None:
+        """Enqueue n_steps fused steps (no host synchronisation)."""
+        if n_steps <= 0:
+            return
+        ptrwm_hip.run(
+            self.target, self.proposal, state=self.state, logp=self.logp, beta=self.beta, step0=self.steps_done,
+            n_steps=n_steps, burn_in=self.burn_in, swap_every=self.swap_every, swap_mode=self.swap_mode,
+            swap_order=self.swap_order, seed=self.seed, chain_offset=self.chain_offset, n_accept=self.n_accept,
+            sq_jump=self.sq_jump, swap_accept=self.swap_accept, last_swap_ordinal=self.last_ord, trace=trace,
+            trace_logp=trace_logp, trace_row0=trace_row0,
+        )
+        self.steps_done += n_steps
+
+    # ---- summaries (each read synchronises) ---------------------------------------------------
+    @property
+    def post_burn_steps(self) -> int:
+        return max(0, self.steps_done - self.burn_in)
+
+    def swap_events(self) -> int:
+        e = self.steps_done // self.swap_every - self.burn_in // self.swap_every
+        return max(0, e) if self.n_temps > 1 else 0
+
+    def swap_attempts_per_replica(self) -> int:
+        """Swap attempts one ladder has made so far (deterministic, needs no device read)."""
+        ev, T = self.swap_events(), self.n_temps
+        if self.swap_order == ptrwm_hip.ORDER_SEQUENTIAL:
+            return ev * (T - 1)
+        n_even, n_odd = (T - 1 + 1) // 2, (T - 1) // 2  # pairs with even / odd lower index
+        # events are numbered from 0: even-numbered events take the even pairs
+        return ((ev + 1) // 2) * n_even + (ev // 2) * n_odd
+
+    def summary(self) -> dict:
+        """Whole-shard sums, as plain Python numbers / CPU tensors (one device sync)."""
+        acc = self.n_accept.sum(0).cpu()
+        sq = self.sq_jump.sum(0).cpu()
+        sw = self.swap_accept.sum(0).cpu()
+        return {
+            "n_replicas": self.n_replicas,
+            "post_burn_steps": self.post_burn_steps,
+            "accept_count": acc,            # [T] int64
+            "sq_jump_sum": sq,              # [T] float64
+            "swap_accept_count": sw,        # [T] int64 (last entry unused)
+            "swap_attempts": self.swap_attempts_per_replica() * self.n_replicas,
+        }
