@@ -1,0 +1,296 @@
+"""The drop-in Python classes on a real GPU: reference API shapes/attributes, statistical checks modelled on the
+reference's own script-style tests (tests/test_rwm_correctness.py, tests/test_pt_gpu_optimizations.py,
+tests/test_proposals.py), and BASELINE-size property tests.  Run with `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from algorithms import (ParallelTemperingRWM_GPU_Optimized, RandomWalkMH_GPU_Optimized, geometric_beta_ladder,
+                        ultra_fused_mcmc_step_basic)
+from interfaces import MCMCSimulation_GPU
+from oracle import oracle as O
+from proposal_distributions import LaplaceProposal, NormalProposal, UniformRadiusProposal
+from target_distributions import (EvenRosenbrockTorch, FullRosenbrockTorch, HybridRosenbrockTorch, IIDBetaTorch,
+                                  IIDGammaTorch, RoughCarpetDistributionTorch, ThreeMixtureDistributionTorch)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_target_classes_reproduce_reference_log_density(device):
+    """Each class, built from the constructor arguments the golden targets were built with, returns the reference's
+    numbers (single point -> scalar, batch -> vector; test_torch_distributions.py:110-122)."""
+    G = H.golden_targets()
+    c15 = [[-15.0] + [0.0] * 29, [0.0] * 30, [15.0] + [0.0] * 29]
+    built = {
+        "rc15_d30": RoughCarpetDistributionTorch(30, device=device, mode_centers=[-15.0, 0.0, 15.0]),
+        "rc5_d30": RoughCarpetDistributionTorch(30, device=device),
+        "rc4_d20": RoughCarpetDistributionTorch(20, device=device, mode_centers=[-4.0, 0.0, 4.0],
+                                                mode_weights=[0.2, 0.5, 0.3]),
+        "tm_d50": ThreeMixtureDistributionTorch(50, device=device),
+        "tm15_d30": ThreeMixtureDistributionTorch(30, device=device, mode_centers=c15),
+        "full_d30": FullRosenbrockTorch(30, device=device),
+        "full_d10": FullRosenbrockTorch(10, a_coeff=0.1, b_coeff=2.0, mu=torch.linspace(0.5, 1.5, 9), device=device),
+        "even_d30": EvenRosenbrockTorch(30, device=device),
+        "hyb_3_5": HybridRosenbrockTorch(3, 5, device=device),
+        "hyb_5_4": HybridRosenbrockTorch(5, 4, device=device),
+        "gamma_d50": IIDGammaTorch(50, device=device),
+        "gamma_d5": IIDGammaTorch(5, shape=3.5, scale=0.7, device=device),
+        "beta_d50": IIDBetaTorch(50, device=device),
+        "beta_d5": IIDBetaTorch(5, alpha=1.5, beta=4.0, device=device),
+    }
+    for key, t in built.items():
+        spec, x, ref, meta = G[key]
+        assert t.get_name() == meta["name"]
+        got = t.log_density(torch.tensor(x, device=device))
+        assert got.shape == (x.shape[0],) and got.dtype == torch.float32
+        got = got.cpu().numpy()
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+        assert np.max(np.abs(got[fin] - ref[fin]) / np.maximum(1, np.abs(ref[fin]))) < 1e-5, key
+        one = t.log_density(torch.tensor(x[5], device=device))
+        assert one.shape == () and float(one) == pytest.approx(float(got[5]), rel=1e-6, abs=1e-6)
+        d = t.density(torch.tensor(x[:8], device=device))
+        assert torch.allclose(d, torch.exp(t.log_density(torch.tensor(x[:8], device=device))))
+    # scaled variants draw their own factors: check against the oracle with those factors
+    for t in (RoughCarpetDistributionTorch(10, scaling=True, device=device),
+              ThreeMixtureDistributionTorch(10, scaling=True, device=device)):
+        assert t.get_name().endswith("Scaled")
+        x = np.random.default_rng(0).normal(0, 4, (50, 10)).astype(np.float32)
+        et = t.engine_target()
+        ot = O.Target(et.kind, et.dim, et.p, et.ip, None if et.vec0 is None else et.vec0.cpu().numpy(),
+                      None if et.vec1 is None else et.vec1.cpu().numpy())
+        want = O.logdensity(ot, x, "f64")
+        got = t.log_density(torch.tensor(x, device=device)).cpu().numpy()
+        assert np.max(np.abs(got - want) / np.maximum(1, np.abs(want))) < 1e-5
+
+
+def test_rwm_class_api_and_statistics(device):
+    """Shapes, counters and the statistical bounds of tests/test_rwm_correctness.py (:66, :108, :207, :715)."""
+    torch.manual_seed(0)
+    np.random.seed(0)
+    dim, N, burn = 30, 20000, 1000
+    target = RoughCarpetDistributionTorch(dim, device=device, mode_centers=[-15.0, 0.0, 15.0])
+    alg = RandomWalkMH_GPU_Optimized(dim, 2.38**2 / dim, target, burn_in=burn, device=device, pre_allocate_steps=N)
+    assert alg.get_name() == "RWM_GPU_FUSED_Normal"
+    assert alg.acceptance_rate == 0.0 and alg.chain_index == 0
+    out = alg.generate_samples(N)
+    assert out.shape == (N, dim) and out.is_cuda
+    assert alg.total_steps == N + burn and alg.chain_index == N + burn + 1
+    assert alg.get_chain_gpu().shape == (N + burn + 1, dim)
+    assert alg.get_log_densities_gpu().shape == (N + burn + 1,)
+    chain = alg.get_chain_gpu()
+    assert torch.equal(chain[-1], alg.current_state)
+    # stored log-densities are the log-densities of the stored states
+    lp = target.log_density(chain[-50:])
+    assert torch.allclose(lp, alg.get_log_densities_gpu()[-50:], atol=1e-3)
+    # acceptance counted after burn-in only, consistent with the stored chain
+    moved = (chain[1 + burn:] != chain[burn:-1]).any(dim=1)
+    assert int(moved.sum()) == alg.num_acceptances
+    assert alg.acceptance_rate == pytest.approx(alg.num_acceptances / N)
+    assert 0.15 < alg.acceptance_rate < 0.35  # 2.38^2/d scaling: near 0.234
+    # ESJD equals the reference formula on the stored chain (rwm_gpu_optimized.py:513-534)
+    post = chain[burn:]
+    want = torch.mean(torch.sum((post[1:] - post[:-1]) ** 2, dim=1)).item()
+    assert alg.expected_squared_jump_distance_gpu() == pytest.approx(want, rel=1e-4)
+    # sequential dependence: lag-1 autocorrelation strictly inside (0.05, 0.95) ... for a mixing coordinate
+    x = out[:, 0].double().cpu().numpy()
+    ac = np.corrcoef(x[:-1], x[1:])[0, 1]
+    assert 0.05 < ac < 0.9999
+    info = alg.get_diagnostic_info()
+    assert info["total_steps"] == N + burn and "kernel_fusion" in info
+    alg.reset()
+    assert alg.total_steps == 0 and alg.chain_index == 0 and alg.acceptance_rate == 0.0
+    alg.step()
+    alg.step()
+    assert alg.total_steps == 2 and alg.chain_index == 3
+
+
+def test_rwm_matches_oracle_statistics_many_chains(device):
+    """65 536 chains x 300 steps on the GPU vs the oracle on a bounded sample of the SAME chains (same seed,
+    same chain ids): acceptance rate and ESJD within 1e-3 relative on the common chains (BASELINE parity bar)."""
+    dim = 30
+    target = RoughCarpetDistributionTorch(dim, device=device, mode_centers=[-15.0, 0.0, 15.0])
+    C, N, burn, seed = 65536, 300, 50, 20240607
+    alg = RandomWalkMH_GPU_Optimized(dim, 2.38**2 / dim, target, burn_in=burn, device=device, num_chains=C, seed=seed)
+    alg.generate_samples(N)
+    run = alg._run
+    n_cmp = 2048
+    spec = H.target_spec("rc15_d30")
+    prop = H.proposal_spec("Normal", dim, [1.0], base_variance_scalar=2.38**2 / dim, single=True)
+    st = np.zeros((n_cmp, 1, dim), np.float32)
+    lp = np.tile(O.logdensity(spec.oracle(), np.zeros((1, dim), np.float32)).astype(np.float32), (n_cmp, 1))
+    want = O.run(spec.oracle(), prop.oracle(), state=st, logp=lp, beta=[1.0], step0=0, n_steps=N + burn, burn_in=burn,
+                 seed=seed)
+    g_acc = run.n_accept[:n_cmp, 0].cpu().numpy()
+    g_sq = run.sq_jump[:n_cmp, 0].cpu().numpy()
+    assert g_acc.sum() / want["n_accept"].sum() == pytest.approx(1.0, rel=1e-3)
+    assert g_sq.sum() / want["sq_jump"].sum() == pytest.approx(1.0, rel=1e-3)
+    # most chains agree exactly (a chain differs only after a fp32-level decision flip)
+    assert np.mean(g_acc == want["n_accept"][:, 0]) > 0.97
+    # whole-population acceptance is consistent with the sample (binomial CI)
+    p_all = alg.acceptance_rate
+    p_s = want["n_accept"].sum() / (n_cmp * N)
+    assert abs(p_all - p_s) < 5 * np.sqrt(p_s * (1 - p_s) / (n_cmp * N) * 10)  # x10: within-chain autocorrelation
+
+
+@pytest.mark.parametrize("name,params", [
+    ("Normal", {"base_variance_scalar": 0.2}),
+    ("Laplace", {"base_variance_vector": [0.2] * 10}),
+    ("UniformRadius", {"base_radius": 1.5}),
+])
+def test_simulation_harness_with_each_proposal(device, name, params):
+    """tests/test_proposals.py:228-247: MCMCSimulation_GPU with each proposal_config."""
+    dim = 10
+    target = ThreeMixtureDistributionTorch(dim, device=device)
+    sim = MCMCSimulation_GPU(dim=dim, proposal_config={"name": name, "params": params}, num_iterations=4000,
+                             algorithm=RandomWalkMH_GPU_Optimized, target_dist=target, seed=3, burn_in=500,
+                             device=str(device))
+    assert not sim.has_run()
+    with pytest.raises(ValueError):
+        sim.acceptance_rate()
+    chain = sim.generate_samples(progress_bar=False)
+    assert isinstance(chain, list) and len(chain) == 4000 and len(chain[0]) == dim
+    assert sim.has_run() and 0.02 < sim.acceptance_rate() < 0.98
+    assert sim.expected_squared_jump_distance() > 0
+    assert sim.algorithm.get_name() == f"RWM_GPU_FUSED_{name}"
+    with pytest.raises(ValueError):
+        sim.generate_samples()
+    # same seed -> same run (the harness seeds torch after building the sampler)
+    sim2 = MCMCSimulation_GPU(dim=dim, proposal_config={"name": name, "params": params}, num_iterations=4000,
+                              algorithm=RandomWalkMH_GPU_Optimized, target_dist=target, seed=3, burn_in=500,
+                              device=str(device))
+    chain2 = sim2.generate_samples(progress_bar=False)
+    assert chain2 == chain
+
+
+def test_pt_class_api_and_statistics(device):
+    """tests/test_pt_gpu_optimizations.py:91-93, :296-297: swap attempts, swap rate, cold-chain moments."""
+    torch.manual_seed(1)
+    np.random.seed(1)
+    dim, N, burn, se = 8, 20000, 1000, 10
+    target = ThreeMixtureDistributionTorch(dim, device=device)  # modes at (-5,0..), 0, (5,0..)
+    alg = ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target, geom_temp_spacing=True, swap_every=se,
+                                             burn_in=burn, device=device, pre_allocate_steps=N)
+    assert alg.num_chains == 8 and alg.beta_ladder[0] == 1.0 and alg.beta_ladder[-1] == 0.01
+    assert alg.get_name() == "PT_RWM_GPU_ULTRA_FUSED"
+    cold = alg.generate_samples(N)
+    assert cold.shape == (N, dim)
+    assert alg.step_counter == N + burn
+    expected_attempts = ((N + burn) // se - burn // se) * 7
+    assert alg.num_swap_attempts == expected_attempts
+    assert alg.num_swap_acceptances > 0.05 * expected_attempts
+    assert 0.05 < alg.swap_acceptance_rate <= 1.0
+    assert alg.pt_esjd > 0
+    chains = alg.get_all_chains_gpu()
+    assert len(chains) == 8 and all(c.shape == (N + burn + 1, dim) for c in chains)
+    assert torch.equal(alg.get_cold_chain_gpu(), chains[0])
+    assert alg.current_states.shape == (8, dim) and alg.current_log_densities.shape == (8,)
+    assert torch.equal(chains[3][-1], alg.current_states[3])
+    assert len(alg.chain) == N + burn + 1
+    # the cold chain visits all three modes and has the mixture's moments: mean 0, var(x0) = 1 + 50/3
+    x0 = cold[:, 0].double()
+    assert (x0 < -2.5).float().mean() > 0.1 and (x0 > 2.5).float().mean() > 0.1
+    assert abs(cold.mean(0)).max() < 1.5
+    assert torch.isfinite(cold).all() and cold.std(0).min() > 0.1
+    # cold ESJD from the kernel == reference formula on the stored cold chain (pt_rwm_gpu_optimized.py:772-789)
+    post = alg.get_cold_chain_gpu()[burn:]
+    want = torch.mean(torch.sum((post[1:] - post[:-1]) ** 2, dim=1)).item()
+    assert alg.expected_squared_jump_distance_gpu() == pytest.approx(want, rel=1e-4)
+    rates = alg.mh_acceptance_rates()
+    assert rates.shape == (8,) and (rates > 0.01).all() and (rates < 0.99).all()
+    info = alg.get_diagnostic_info()
+    for k in ("batch_matrix_multiply", "precomputed_randoms", "clone_free_swaps", "kernel_fusion", "memory_allocated_mb"):
+        assert k in info  # read by the reference's quick_test_optimizations.py:94-99
+    alg.reset()
+    assert alg.step_counter == 0 and alg.num_swap_attempts == 0
+    alg.step()
+    assert alg.step_counter == 1
+
+
+def test_pt_reference_run_through_the_class(device):
+    """The golden PT run cannot be replayed through the class (it draws Philox randoms), but its configuration can:
+    same ladder/schedule, swap_mode='reference_copy' -> the documented statistics identities hold."""
+    z = H.load("pt_rc15_geo8.npz")
+    target = RoughCarpetDistributionTorch(30, device=device, mode_centers=[-15.0, 0.0, 15.0])
+    alg = ParallelTemperingRWM_GPU_Optimized(30, float(z["var"]), target, beta_ladder=list(z["beta_ladder"]),
+                                             swap_every=int(z["swap_every"]), burn_in=int(z["burn_in"]), device=device,
+                                             pre_allocate_steps=int(z["n_samples"]), swap_mode="reference_copy", seed=9)
+    alg.generate_samples(int(z["n_samples"]))
+    assert alg.num_swap_attempts == int(z["num_swap_attempts"])
+    last = int(alg._run.last_ord.max())
+    assert alg.swap_acceptance_rate == pytest.approx(alg.num_swap_acceptances / last)
+    assert alg.pt_esjd == pytest.approx(alg.squared_jump_distances / last)
+
+
+def test_pt_iterative_ladder_on_device(device):
+    """Iterative (Robbins-Monro) ladder: adjacent estimated swap rates land near the 0.234 target."""
+    torch.manual_seed(5)
+    target = RoughCarpetDistributionTorch(10, device=device)
+    alg = ParallelTemperingRWM_GPU_Optimized(10, 0.5, target, iterative_temp_spacing=True, N_samples_swap_est=20000,
+                                             swap_every=5, device=device)
+    lad = alg.beta_ladder
+    assert alg.get_name() == "PT_RWM_GPU_ULTRA_FUSED_ITERATIVE_LADDER"
+    assert lad[0] == 1.0 and lad[-1] == pytest.approx(0.01) and all(a > b for a, b in zip(lad, lad[1:]))
+    assert 3 <= len(lad) <= 64
+    for hi, lo in list(zip(lad, lad[1:]))[:-1]:
+        assert abs(alg._estimate_swap_rate(hi, lo, 50000) - 0.234) < 0.03
+
+
+def test_baseline_config3_properties(device):
+    """BASELINE.json configs[2] at full size: RoughCarpet dim 30, 32 geometric temperatures, swap_every 10,
+    65 536 ladders.  Size-independent properties: determinism, exchange conserves the replica multiset,
+    swap attempt arithmetic, acceptance within the oracle's CI, statistics only after burn-in."""
+    dim, T, C = 30, 32, 65536
+    target = RoughCarpetDistributionTorch(dim, device=device, mode_centers=[-15.0, 0.0, 15.0])
+    ladder = geometric_beta_ladder(T)
+
+    def make(order="sequential", seed=4242):
+        return ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target, beta_ladder=ladder, swap_every=10,
+                                                  burn_in=20, device=device, num_replicas=C, seed=seed, trace="none",
+                                                  swap_order=order)
+
+    a, b = make(), make()
+    a.generate_samples(80)
+    b._advance(37)
+    b._advance(63)
+    assert torch.equal(a._run.state, b._run.state)  # deterministic, and launch boundaries are invisible
+    assert torch.equal(a._run.n_accept, b._run.n_accept) and torch.equal(a._run.swap_accept, b._run.swap_accept)
+    assert a.num_swap_attempts == 8 * 31 * C  # events at steps 30..100
+    assert int(a._run.swap_accept[:, -1].sum()) == 0
+    assert torch.isfinite(a._run.state).all()
+    # log-densities carried by the kernel are those of the carried states
+    lp = target.log_density(a._run.state[:512].reshape(-1, dim)).view(512, T)
+    assert torch.allclose(lp, a._run.logp[:512], atol=2e-3)
+    # oracle on the first 64 ladders, same seed: acceptance and swap counts within 1e-3 / CI
+    spec = H.target_spec("rc15_d30")
+    prop = H.proposal_spec("Normal", dim, ladder, base_variance_scalar=2.38**2 / dim)
+    n_cmp = 64
+    st = np.zeros((n_cmp, T, dim), np.float32)
+    lp0 = np.tile(O.logdensity(spec.oracle(), np.zeros((1, dim), np.float32)).astype(np.float32), (n_cmp, T))
+    want = O.run(spec.oracle(), prop.oracle(), state=st, logp=lp0, beta=np.float32(ladder), step0=0, n_steps=100,
+                 burn_in=20, swap_every=10, seed=4242)
+    g_acc = a._run.n_accept[:n_cmp].cpu().numpy()
+    assert g_acc.sum() / want["n_accept"].sum() == pytest.approx(1.0, rel=2e-3)
+    assert a._run.swap_accept[:n_cmp].sum().item() / want["swap_accept"].sum() == pytest.approx(1.0, rel=5e-3)
+    assert np.mean(g_acc == want["n_accept"]) > 0.9
+    # even/odd: half the pairs per event
+    e = make("even_odd")
+    e.generate_samples(80)
+    assert e.num_swap_attempts == (4 * 16 + 4 * 15) * C
+    rates = e.mh_acceptance_rates()
+    assert ((rates > 0.1) & (rates < 0.6)).all()
+
+
+def test_fused_step_helper_matches_kernel_rule(device):
+    """tests/test_rwm_correctness.py:310-316 calls ultra_fused_mcmc_step_basic directly: shapes and dtypes."""
+    x = torch.zeros(5, device=device)
+    inc = torch.ones(5, device=device)
+    new, lp, acc = ultra_fused_mcmc_step_basic(x, torch.tensor(-3.0, device=device), inc,
+                                               torch.tensor(0.5, device=device), torch.tensor(1.0, device=device),
+                                               torch.tensor(-2.0, device=device))
+    assert new.shape == (5,) and bool(acc) and float(lp) == -2.0 and torch.equal(new, inc)
+    new, lp, acc = ultra_fused_mcmc_step_basic(x, torch.tensor(-3.0, device=device), inc,
+                                               torch.tensor(0.9, device=device), torch.tensor(1.0, device=device),
+                                               torch.tensor(-float("inf"), device=device))
+    assert not bool(acc) and torch.equal(new, x)

@@ -1,0 +1,404 @@
+"""Parity of the HIP engine, called through its C ABI (include/ptrwm.h), against the reference's golden
+vectors and against the CPU oracle on seeded inputs.  Needs an MI355X: run with `-m gpu`.
+
+Tolerances (stated once):
+  * integer / index work (Philox words, accept counts given equal decisions, swap bookkeeping): exact
+  * state updates x + scale*z (Normal proposal): bit-exact IEEE single
+  * log-densities: |gpu - fp64 oracle| <= 4e-6 * max(1, |log p|) + 1e-4  (fp32 evaluation; v_exp/v_log 1 ulp)
+  * accept decisions: can only differ where |u - exp(r)| is inside that error; checked one step at a time
+    ("teacher forced") so one flip cannot cascade, agreement >= 99.9 % required
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+import ptrwm_hip as E
+from oracle import oracle as O
+from test_oracle_golden import PT_CASES, RWM_CASES, TARGET_KEYS, pt_case, rwm_case
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_t(a, device, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), device=device, dtype=dtype)
+
+
+def gpu_run(spec, prop, device, *, state, logp, beta, n_steps, trace_temps=0, want_flags=False, ext_prop=None,
+            ext_u=None, ext_swap_u=None, **kw):
+    """Mirror of oracle.run for the engine: returns numpy results."""
+    Cn, T, D = state.shape
+    st, lp = dev_t(state, device), dev_t(logp, device).reshape(Cn, T).contiguous()
+    res = {
+        "n_accept": torch.zeros(Cn, T, dtype=torch.int64, device=device),
+        "sq_jump": torch.zeros(Cn, T, dtype=torch.float64, device=device),
+        "swap_accept": torch.zeros(Cn, T, dtype=torch.int64, device=device),
+        "last_swap_ordinal": torch.zeros(Cn, T, dtype=torch.int64, device=device),
+    }
+    trace = trace_logp = flags = None
+    if trace_temps:
+        trace = torch.zeros(n_steps, Cn, trace_temps, D, device=device)
+        trace_logp = torch.zeros(n_steps, Cn, trace_temps, device=device)
+    if want_flags:
+        flags = torch.zeros(n_steps, Cn, T, dtype=torch.uint8, device=device)
+    E.run(spec.engine(device), prop.engine(device), state=st, logp=lp, beta=dev_t(beta, device), n_steps=n_steps,
+          n_accept=res["n_accept"], sq_jump=res["sq_jump"], swap_accept=res["swap_accept"],
+          last_swap_ordinal=res["last_swap_ordinal"], trace=trace, trace_logp=trace_logp, accept_flags=flags,
+          ext_prop=None if ext_prop is None else dev_t(ext_prop, device),
+          ext_u=None if ext_u is None else dev_t(ext_u, device),
+          ext_swap_u=None if ext_swap_u is None else dev_t(ext_swap_u, device), **kw)
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy() for k, v in res.items()}
+    out["state"], out["logp"] = st.cpu().numpy(), lp.cpu().numpy()
+    if trace is not None:
+        out["trace"], out["trace_logp"] = trace.cpu().numpy(), trace_logp.cpu().numpy()
+    if flags is not None:
+        out["accept_flags"] = flags.cpu().numpy()
+    return out
+
+
+def logp_close(got, want, extra_abs=1e-4):
+    want = np.asarray(want, dtype=np.float64)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isneginf(got), np.isneginf(want))
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    err = np.abs(np.asarray(got, np.float64)[fin] - want[fin])
+    assert np.all(err <= 4e-6 * np.maximum(1, np.abs(want[fin])) + extra_abs), float(err.max())
+
+
+# ---------------------------------------------------------------------------------------------------------
+def test_philox_known_answers(device):
+    for ctr, key, want in (
+        ((0, 0, 0, 0), 0, (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+        ((0xFFFFFFFF,) * 4, 0xFFFFFFFFFFFFFFFF, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+        ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0x299F31D0 << 32) | 0xA4093822,
+         (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)),
+    ):
+        got = E.philox_raw(key, *ctr, 1, device).cpu().numpy()[0]
+        assert tuple(int(v) for v in got) == want
+
+
+def test_philox_blocks_match_oracle(device):
+    got = E.philox_raw(0x0123456789ABCDEF, 5, 77, 123456, 9, 4096, device).cpu().numpy()
+    for i in (0, 1, 63, 64, 4095):
+        assert list(got[i]) == O.philox4x32_10([5 + i, 77, 123456, 9], [0x89ABCDEF, 0x01234567])
+
+
+@pytest.mark.parametrize("key", TARGET_KEYS)
+def test_logdensity_matches_reference_and_oracle(device, key):
+    spec, x, ref, _ = H.golden_targets()[key]
+    got = E.logdensity(spec.engine(device), dev_t(x, device)).cpu().numpy()
+    logp_close(got, ref)                                          # the reference's own fp32 numbers
+    logp_close(got, O.logdensity(spec.oracle(), x, "f64"))        # fp64 truth
+
+
+@pytest.mark.parametrize("key", ["rc15_d30", "tm_d50", "even_d30", "hyb_5_4", "gamma_d50", "beta_d50"])
+def test_logdensity_large_batch_vs_oracle(device, key):
+    """100 000 random states (the survey's tolerance experiment, section 8c)."""
+    spec = H.target_spec(key)
+    rng = np.random.default_rng(5)
+    n = 100_000
+    if key.startswith("beta"):
+        x = rng.uniform(0.001, 0.999, (n, spec.dim))
+    elif key.startswith("gamma"):
+        x = rng.gamma(2.0, 3.0, (n, spec.dim))
+    elif key.startswith(("even", "hyb")):
+        x = rng.normal(0.8, 0.6, (n, spec.dim))
+    else:
+        x = rng.choice([-15.0, -5.0, 0.0, 5.0, 15.0], (n, spec.dim)) + rng.normal(0, 1.5, (n, spec.dim))
+    x = x.astype(np.float32)
+    got = E.logdensity(spec.engine(device), dev_t(x, device)).cpu().numpy()
+    logp_close(got, O.logdensity(spec.oracle(), x, "f64"))
+
+
+def test_logdensity_edge_values(device):
+    spec = H.target_spec("rc15_d30")
+    x = np.zeros((4, 30), np.float32)
+    x[1, 3] = np.inf
+    x[2, 0] = np.nan
+    x[3] = 1e30
+    got = E.logdensity(spec.engine(device), dev_t(x, device)).cpu().numpy()
+    assert np.isfinite(got[0]) and not np.isfinite(got[1]) and np.isnan(got[2]) and got[3] < -1e30
+    assert E.logdensity(spec.engine(device), torch.zeros(0, 30, device=device)).shape == (0,)
+
+
+@pytest.mark.parametrize("tag", ["d30_b1.0", "d7_b0.37", "d50_b0.01"])
+def test_proposal_transforms_match_reference(device, tag):
+    z = H.load("proposals.npz")
+    D = int(tag[1:tag.index("_")])
+    raw, inc = z[f"normal_{tag}__raw"], z[f"normal_{tag}__inc"]
+    p = H.ProposalSpec(O.PROPOSAL_NORMAL, np.array([z[f"normal_{tag}__std"]]))
+    got = E.propose(p.engine(device), D, raw.shape[0], ext_raw=dev_t(raw[:, None, :], device)).cpu().numpy()[:, 0]
+    assert np.array_equal(got, inc)  # bit exact
+
+    raw, inc = z[f"laplace_{tag}__raw"], z[f"laplace_{tag}__inc"]
+    p = H.ProposalSpec(O.PROPOSAL_LAPLACE, np.ones(1, np.float32), z[f"laplace_{tag}__scale"])
+    got = E.propose(p.engine(device), D, raw.shape[0], ext_raw=dev_t(raw[:, None, :], device)).cpu().numpy()[:, 0]
+    np.testing.assert_allclose(got, inc, rtol=2e-6, atol=1e-8)  # v_log_f32 in place of log1p
+
+    raw, inc = z[f"uniform_{tag}__raw"], z[f"uniform_{tag}__inc"]
+    p = H.ProposalSpec(O.PROPOSAL_UNIFORM_RADIUS, np.array([z[f"uniform_{tag}__radius"]]), None, 1.0 / D)
+    got = E.propose(p.engine(device), D, raw.shape[0], ext_raw=dev_t(raw[:, None, :], device)).cpu().numpy()[:, 0]
+    np.testing.assert_allclose(got, inc, rtol=5e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("kind,dim", [("Normal", 30), ("Normal", 7), ("Laplace", 30), ("Laplace", 13),
+                                      ("UniformRadius", 50), ("UniformRadius", 5)])
+def test_philox_proposals_match_oracle_and_moments(device, kind, dim):
+    """In-kernel Philox draws: same words, same transforms as the oracle restatement; and the moments the
+    reference's tests/test_proposals.py:160-210 check (variance = base/beta, radius <= R)."""
+    betas = [1.0, 0.3, 0.05]
+    kw = dict(base_variance_scalar=0.4, base_variance_vector=np.linspace(0.1, 0.9, dim), base_radius=1.3)
+    kw = {k: v for k, v in kw.items() if (kind == "Normal" and k == "base_variance_scalar")
+          or (kind == "Laplace" and k == "base_variance_vector") or (kind == "UniformRadius" and k == "base_radius")}
+    p = H.proposal_spec(kind, dim, betas, **kw)
+    n = 20000
+    got = E.propose(p.engine(device), dim, n, seed=99).cpu().numpy()
+    want = O.propose(p.oracle(), dim, 512, seed=99, precision="f64")
+    # hardware sin/cos/log vs libm in fp64: absolute 2e-6 of the per-temperature scale
+    scale = np.abs(want).max(axis=(0, 2), keepdims=True)
+    assert np.max(np.abs(got[:512] - want) / scale) < 5e-6
+    for t, b in enumerate(betas):
+        if kind == "Normal":
+            assert got[:, t].var() == pytest.approx(0.4 / b, rel=0.02)
+        elif kind == "Laplace":
+            np.testing.assert_allclose(got[:, t].var(axis=0), np.linspace(0.1, 0.9, dim) / b, rtol=0.08)
+        else:
+            r = np.linalg.norm(got[:, t], axis=1)
+            R = 1.3 / np.sqrt(b)
+            assert r.max() <= R * (1 + 1e-5)
+            assert np.mean(r**dim) / R**dim == pytest.approx(0.5, abs=0.02)  # (r/R)^d is U(0,1)
+        assert abs(got[:, t].mean()) < 4 * np.sqrt(got[:, t].var() / (n * dim)) + 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", RWM_CASES)
+def test_rwm_trajectory_matches_reference(device, name):
+    """The reference's stored chain, its random tensors fed to the kernel.  Every golden step is replayed as an
+    independent one-step problem (state_i, randoms_i) -> state_{i+1}: decisions agree >= 99.9 %; where the
+    decision agrees the new state is the reference's."""
+    z, spec, prop, beta = rwm_case(name)
+    chain, lchain = z["chain"], z["logp_chain"]
+    total = chain.shape[0] - 1
+    res = gpu_run(spec, prop, device, state=chain[:-1][:, None, :], logp=lchain[:-1][:, None], beta=[beta], step0=0,
+                  n_steps=1, ext_prop=z["raw"][None, :, None, :], ext_u=z["u"][None, :, None], want_flags=True)
+    moved = np.any(chain[1:] != chain[:-1], axis=1)
+    agree = res["accept_flags"][0, :, 0].astype(bool) == moved
+    assert agree.mean() >= 0.999, f"{name}: {np.sum(~agree)} of {total} decisions differ"
+    exact = str(z["proposal_kind"]) == "Normal"
+    got, want = res["state"][agree, 0], chain[1:][agree]
+    if exact:
+        assert np.array_equal(got, want)
+    else:
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+    logp_close(res["logp"][agree, 0], lchain[1:][agree])
+
+    # free run from the initial state: identical to the reference up to the first flipped decision (if any)
+    lp0 = E.logdensity(spec.engine(device), dev_t(chain[:1], device)).cpu().numpy().reshape(1, 1)
+    burn = int(z["burn_in"])
+    free = gpu_run(spec, prop, device, state=chain[:1][None], logp=lp0, beta=[beta], step0=0, n_steps=total,
+                   burn_in=burn, ext_prop=z["raw"][:, None, None, :], ext_u=z["u"][:, None, None], trace_temps=1,
+                   want_flags=True)
+    first = H.first_mismatch(free["accept_flags"][:, 0, 0].astype(bool), moved)
+    upto = total if first is None else first
+    if exact:
+        assert np.array_equal(free["trace"][:upto, 0, 0], chain[1:upto + 1])
+    else:
+        np.testing.assert_allclose(free["trace"][:upto, 0, 0], chain[1:upto + 1], rtol=1e-4, atol=1e-5)
+    if first is None:
+        N = int(z["n_samples"])
+        assert int(free["n_accept"][0, 0]) == int(z["num_acceptances"])
+        assert free["sq_jump"][0, 0] / N == pytest.approx(float(z["esjd"]), rel=1e-4)
+    else:  # a flip must sit where u is within the fp32 error of exp(r)
+        assert first > 20 or not exact
+
+
+@pytest.mark.parametrize("name", PT_CASES)
+def test_pt_trajectory_matches_reference(device, name):
+    """Reference PT run (sequential sweep, Q1 row copy) replayed on the GPU from the reference's random tensors:
+    teacher-forced per swap period, then free-running."""
+    z, spec, prop, beta = pt_case(name)
+    chains, lchains = z["chains"], z["logp_chains"]  # [T, total+1, D], [T, total+1]
+    T, rows, D = chains.shape
+    total, burn, se = rows - 1, int(z["burn_in"]), int(z["swap_every"])
+    kw = dict(beta=beta, burn_in=burn, swap_every=se, swap_mode=E.SWAP_REFERENCE_COPY, swap_order=E.ORDER_SEQUENTIAL)
+
+    free = gpu_run(spec, prop, device, state=np.ascontiguousarray(chains[:, 0])[None], logp=lchains[:, 0][None],
+                   step0=0, n_steps=total, ext_prop=z["ext_prop"][:, None], ext_u=z["ext_u"][:, None],
+                   ext_swap_u=z["ext_swap_u"][:, None], trace_temps=T, **kw)
+    got = free["trace"][:, 0]  # [total, T, D]
+    want = chains[:, 1:].transpose(1, 0, 2)
+    first = H.first_mismatch(got, want)
+    if first is None:
+        assert int(free["swap_accept"].sum()) == int(z["num_swap_acceptances"])
+        last = int(free["last_swap_ordinal"].max())
+        assert free["swap_accept"].sum() / last == pytest.approx(float(z["swap_acceptance_rate"]), rel=1e-12)
+        b = z["beta_ladder"]
+        sq = float((free["swap_accept"][0, :-1] * (b[:-1] - b[1:]) ** 2).sum())
+        assert sq / last == pytest.approx(float(z["pt_esjd"]), rel=1e-9)
+        assert free["sq_jump"][0, 0] / (total - burn) == pytest.approx(float(z["esjd"]), rel=1e-4)
+        logp_close(free["trace_logp"][:, 0], lchains[:, 1:].T)
+    else:
+        assert first >= 10, f"{name}: leaves the reference trajectory at step {first}"
+
+    # teacher forced: restart from the reference state at every step i (as replica i), one step each, the
+    # step's place in the swap schedule kept through step0 -- done per residue class so step0 is shared
+    n_bad = n_all = 0
+    ev_of_step = {}
+    e = 0
+    for i in range(total):
+        if (i + 1) % se == 0 and (i + 1) > burn:
+            ev_of_step[i] = e
+            e += 1
+    for i in list(range(0, total, max(1, total // 40))) + sorted(ev_of_step)[:25]:
+        us = None
+        if i in ev_of_step:
+            us = z["ext_swap_u"][ev_of_step[i]][None, None]
+        one = gpu_run(spec, prop, device, state=np.ascontiguousarray(chains[:, i])[None], logp=lchains[:, i][None],
+                      step0=i, n_steps=1, ext_prop=z["ext_prop"][i][None, None], ext_u=z["ext_u"][i][None, None],
+                      ext_swap_u=us, **kw)
+        same = np.all(one["state"][0] == chains[:, i + 1], axis=1)
+        n_bad += int(np.sum(~same))
+        n_all += T
+    assert n_bad / n_all <= 1e-3, f"{name}: {n_bad}/{n_all} teacher-forced replica-steps differ"
+
+
+# ---------------------------------------------------------------------------------------------------------
+SWEEP = [
+    ("rc15_d30", "Normal", 8, 7, dict(base_variance_scalar=2.38**2 / 30)),
+    ("even_d30", "Laplace", 32, 4, dict(base_variance_vector=np.full(30, 0.02))),
+    ("tm_d50", "UniformRadius", 64, 2, dict(base_radius=2.5)),
+    ("hyb_3_5", "Normal", 5, 13, dict(base_variance_scalar=0.03)),      # 5 does not divide 64: idle lanes
+    ("gamma_d5", "Laplace", 3, 30, dict(base_variance_vector=np.full(5, 1.0))),
+    ("beta_d5", "UniformRadius", 1, 70, dict(base_radius=0.3)),          # T = 1: plain RWM, two waves
+    ("full_d10", "Normal", 16, 9, dict(base_variance_scalar=0.02)),
+    ("rc15s_d10", "Normal", 11, 6, dict(base_variance_scalar=0.5)),
+    ("tms_d10", "Laplace", 7, 10, dict(base_variance_vector=np.full(10, 0.5))),
+]
+
+
+def start_state(spec, Cn, T, rng):
+    if spec.cls == "IIDBetaTorch":
+        x0 = rng.uniform(0.2, 0.8, spec.dim)
+    elif spec.cls == "IIDGammaTorch":
+        x0 = 5 + 0.01 * rng.standard_normal(spec.dim)
+    elif "Rosenbrock" in spec.cls:
+        x0 = 1e-8 * rng.standard_normal(spec.dim)
+    else:
+        x0 = np.zeros(spec.dim)
+    st = np.broadcast_to(x0.astype(np.float32), (Cn, T, spec.dim)).copy()
+    lp = np.broadcast_to(O.logdensity(spec.oracle(), x0[None].astype(np.float32)).astype(np.float32), (Cn, T)).copy()
+    return st, lp
+
+
+@pytest.mark.parametrize("tkey,pkind,T,Cn,pkw", SWEEP, ids=[f"{s[0]}-{s[1]}-T{s[2]}" for s in SWEEP])
+@pytest.mark.parametrize("mode", ["exchange", "reference_copy"])
+@pytest.mark.parametrize("order", ["sequential", "even_odd"])
+def test_external_randoms_vs_oracle(device, tkey, pkind, T, Cn, pkw, mode, order):
+    """Every (target, proposal) family, every swap semantics: kernel and oracle consume identical random arrays.
+    Counters must match exactly whenever the decisions match; decisions may differ only by fp32-level flips."""
+    spec = H.target_spec(tkey)
+    rng = np.random.default_rng(zlib.crc32(f"{tkey}-{pkind}-{T}".encode()))
+    beta = (0.05 ** (np.arange(T) / max(1, T - 1))).astype(np.float32)
+    prop = H.proposal_spec(pkind, spec.dim, beta, **pkw)
+    N, burn, se = 120, 17, 6
+    raw = O.ext_raw_per_step(prop.kind, spec.dim)
+    ext = rng.standard_normal((N, Cn, T, raw)).astype(np.float32)
+    if pkind == "Laplace":
+        ext = rng.random((N, Cn, T, raw)).astype(np.float32)
+    elif pkind == "UniformRadius":
+        ext[..., -1] = rng.random((N, Cn, T)).astype(np.float32)
+    u = rng.random((N, Cn, T)).astype(np.float32)
+    n_ev = N // se - burn // se
+    us = rng.random((n_ev, Cn, max(T - 1, 1))).astype(np.float32)[:, :, :T - 1]
+    st, lp = start_state(spec, Cn, T, rng)
+    kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=burn, swap_every=se, ext_prop=ext, ext_u=u,
+              ext_swap_u=us if T > 1 else None, want_flags=True)
+    want = O.run(spec.oracle(), prop.oracle(), swap_mode=E.SWAP_MODES[mode], swap_order=E.SWAP_ORDERS[order],
+                 trace_chains=Cn, trace_temps=T, **kw)
+    got = gpu_run(spec, prop, device, trace_temps=T, swap_mode=E.SWAP_MODES[mode], swap_order=E.SWAP_ORDERS[order], **kw)
+    first = H.first_mismatch(got["accept_flags"], want["accept_flags"])
+    upto = N if first is None else first
+    assert upto >= 10
+    if pkind == "Normal":
+        assert np.array_equal(got["trace"][:upto], want["trace"][:upto])
+    else:
+        np.testing.assert_allclose(got["trace"][:upto], want["trace"][:upto], rtol=1e-4, atol=1e-5)
+    logp_close(got["trace_logp"][:upto], want["trace_logp"][:upto], extra_abs=3e-4)
+    if first is None:
+        for k in ("n_accept", "swap_accept", "last_swap_ordinal"):
+            assert np.array_equal(got[k], want[k]), k
+        np.testing.assert_allclose(got["sq_jump"], want["sq_jump"], rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("tkey,pkind,T,Cn,pkw", SWEEP[:6], ids=[f"{s[0]}-{s[1]}-T{s[2]}" for s in SWEEP[:6]])
+def test_philox_mode_vs_oracle(device, tkey, pkind, T, Cn, pkw):
+    """In-kernel Philox against the oracle's restatement of the same counter layout (same seed, same chain ids):
+    the decision streams agree except for fp32-level flips, the statistics agree to the same degree."""
+    spec = H.target_spec(tkey)
+    beta = (0.05 ** (np.arange(T) / max(1, T - 1))).astype(np.float32)
+    prop = H.proposal_spec(pkind, spec.dim, beta, **pkw)
+    rng = np.random.default_rng(11)
+    st, lp = start_state(spec, Cn, T, rng)
+    N = 60
+    kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=5, swap_every=4, seed=0xC0FFEE1234,
+              chain_offset=1000003, want_flags=True)
+    want = O.run(spec.oracle(), prop.oracle(), **kw)
+    got = gpu_run(spec, prop, device, **kw)
+    agree = (got["accept_flags"] == want["accept_flags"]).mean()
+    assert agree >= 0.995, agree
+    if agree == 1.0:
+        assert np.array_equal(got["n_accept"], want["n_accept"])
+        assert np.array_equal(got["swap_accept"], want["swap_accept"])
+        np.testing.assert_allclose(got["state"], want["state"], rtol=2e-3, atol=2e-4)
+
+
+def test_launch_split_and_resume_are_invisible(device):
+    """n steps in one call == the same steps in several calls (step0 carries the schedule and the RNG position)."""
+    spec = H.target_spec("rc15_d30")
+    T, Cn = 8, 9
+    beta = (0.01 ** (np.arange(T) / (T - 1))).astype(np.float32)
+    prop = H.proposal_spec("Normal", 30, beta, base_variance_scalar=2.38**2 / 30)
+    st, lp = start_state(spec, Cn, T, np.random.default_rng(0))
+    kw = dict(beta=beta, burn_in=13, swap_every=5, seed=77, chain_offset=5)
+    one = gpu_run(spec, prop, device, state=st, logp=lp, step0=0, n_steps=90, **kw)
+    a = gpu_run(spec, prop, device, state=st, logp=lp, step0=0, n_steps=31, **kw)
+    b = gpu_run(spec, prop, device, state=a["state"], logp=a["logp"], step0=31, n_steps=59, **kw)
+    assert np.array_equal(one["state"], b["state"]) and np.array_equal(one["logp"], b["logp"])
+    for k in ("n_accept", "swap_accept"):
+        assert np.array_equal(one[k], a[k] + b[k])
+    assert np.array_equal(one["last_swap_ordinal"], np.maximum(a["last_swap_ordinal"], b["last_swap_ordinal"]))
+
+
+def test_chain_offset_makes_sharding_invisible(device):
+    """Chains [0, 2n) in one call == chains [0, n) and [n, 2n) in two calls with chain_offset (multi-GPU rule)."""
+    spec = H.target_spec("even_d30")
+    T, Cn = 4, 40
+    beta = np.array([1, 0.6, 0.3, 0.1], np.float32)
+    prop = H.proposal_spec("Laplace", 30, beta, base_variance_vector=np.full(30, 0.02))
+    st, lp = start_state(spec, Cn, T, np.random.default_rng(1))
+    kw = dict(beta=beta, step0=0, n_steps=40, burn_in=0, swap_every=3, seed=5)
+    whole = gpu_run(spec, prop, device, state=st, logp=lp, chain_offset=100, **kw)
+    lo = gpu_run(spec, prop, device, state=st[:17], logp=lp[:17], chain_offset=100, **kw)
+    hi = gpu_run(spec, prop, device, state=st[17:], logp=lp[17:], chain_offset=117, **kw)
+    assert np.array_equal(whole["state"], np.concatenate([lo["state"], hi["state"]]))
+    assert np.array_equal(whole["n_accept"], np.concatenate([lo["n_accept"], hi["n_accept"]]))
+
+
+def test_argument_validation_through_the_abi(device):
+    spec = H.target_spec("rc15_d30")
+    prop = H.proposal_spec("Normal", 30, [1.0], base_variance_scalar=0.1)
+    st = torch.zeros(2, 1, 30, device=device)
+    lp = torch.zeros(2, 1, device=device)
+    b = torch.ones(1, device=device)
+    with pytest.raises(E.PTRWMError) as ei:
+        E.run(spec.engine(device), prop.engine(device), state=st, logp=lp, beta=b, step0=0, n_steps=1, swap_every=0)
+    assert ei.value.code == -5
+    with pytest.raises(E.PTRWMError):
+        E.run(spec.engine(device), prop.engine(device), state=st, logp=lp, beta=b, step0=-1, n_steps=1)
+    # zero work is a no-op, not an error
+    E.run(spec.engine(device), prop.engine(device), state=st, logp=lp, beta=b, step0=0, n_steps=0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        E.logdensity(spec.engine(device), torch.zeros(3, 30))
