@@ -1,0 +1,217 @@
+"""Benchmark of the PT-RWM hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A bench "step" is ONE launch of the fused kernel over the rank's whole batch: `--inner` Metropolis steps
+(default 100 = 10 swap periods) for every (ladder, temperature) replica.  Workload = BASELINE.json configs[2], the
+configuration the headline metric is quoted on: PT-RWM, RoughCarpet dim 30 (modes +-15), Normal proposal
+2.38^2/30, 32 geometric temperatures 1 -> 0.01, swap_every 10, 65 536 ladders PER GPU (weak scaling: ranks own
+disjoint blocks of global ladder ids, no collective on the data path; one summary all-reduce at the end).
+
+metric = chain-MH-steps/s: one unit = one (ladder, temperature) replica advancing one Metropolis step.
+Inputs are resident in HBM before the timed region (state is generated on the device).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     dominant kernel (ptrwm_step_kernel): algorithmic bytes per launch / mean launch duration measured
+               with HIP events on the launch stream, against the 8 TB/s HBM peak.  Algorithmic bytes per
+               chain-MH-step = 8*dim + 24 = 264 B (x, log p, accept count, ESJD sum read and
+               written once per step in the streaming formulation).
+  cpu_baseline the NumPy port of the reference's CPU sampler (algorithms/pt_rwm.py) timed on this host, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "rwm-pt-pytorch_amd"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--inner", type=int, default=100, help="Metropolis steps per launch")
+    ap.add_argument("--chains", type=int, default=65536, help="ladders per GPU")
+    ap.add_argument("--temps", type=int, default=32)
+    ap.add_argument("--dim", type=int, default=30)
+    ap.add_argument("--swap-every", type=int, default=10)
+    ap.add_argument("--swap-order", default="sequential", choices=["sequential", "even_odd"])
+    ap.add_argument("--workload", default="pt", choices=["pt", "rwm"], help="rwm = configs[1] (one temperature)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(dim, temps, seconds):
+    """The reference's NumPy CPU path (restated in oracle/numpy_baseline.py, pinned to the reference by
+    tests/test_numpy_baseline.py) on a bounded sample of the same workload: one ladder, this host, one core."""
+    import numpy as np
+
+    from oracle import numpy_baseline as NB
+
+    ladder = [float(0.01 ** (t / (temps - 1))) for t in range(temps)] if temps > 1 else [1.0]
+    np.random.seed(1)
+    if temps > 1:
+        alg = NB.ParallelTemperingNumpy(dim, 2.38**2 / dim, NB.RoughCarpetNumpy(dim), ladder)
+    else:
+        alg = NB.RandomWalkMHNumpy(dim, 2.38**2 / dim, NB.RoughCarpetNumpy(dim))
+    t0 = time.perf_counter()
+    iters = mh_steps = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            alg.step()
+            iters += 1
+            # pt_rwm.py:175-181: on every 20th iteration only the hottest chain moves, the rest attempt swaps
+            mh_steps += 1 if (temps > 1 and iters % NB.ParallelTemperingNumpy.swap_every == 0) else temps
+    dt = time.perf_counter() - t0
+    return {
+        "value": mh_steps / dt, "unit": "chain-MH-steps/s", "cores": 1, "kind": "port",
+        "sample": f"NumPy port of algorithms/{'pt_rwm' if temps > 1 else 'rwm'}.py, RoughCarpet dim {dim}, "
+                  f"{temps} temperature(s), 1 ladder, {iters} iterations in {dt:.1f} s on one host core",
+    }
+
+
+def c_oracle_rate(dim, temps, swap_every):
+    """Extra, informative: the compiled C oracle (fp32, one core) on 8 ladders x 200 steps."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    lw = np.log(np.array([0.5, 0.3, 0.2], dtype=np.float32))
+    ot = O.Target(O.TARGET_ROUGH_CARPET, dim, p=[-15.0, 0.0, 15.0, *lw, 0.0])
+    beta = np.array([0.01 ** (t / max(1, temps - 1)) for t in range(temps)], dtype=np.float32)
+    op = O.Proposal(O.PROPOSAL_NORMAL, np.sqrt((2.38**2 / dim / beta.astype(np.float64)).astype(np.float32)))
+    C, N = 8, 200
+    st = np.zeros((C, temps, dim), np.float32)
+    lp = np.tile(O.logdensity(ot, np.zeros((1, dim), np.float32)).astype(np.float32), (C, temps))
+    t0 = time.perf_counter()
+    O.run(ot, op, state=st, logp=lp, beta=beta, step0=0, n_steps=N, swap_every=swap_every, seed=3)
+    return C * temps * N / (time.perf_counter() - t0)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # convenience: re-launch under torch.distributed.run as a child (nothing has touched the GPU yet)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29531"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import torch.distributed as dist
+
+    from algorithms import ParallelTemperingRWM_GPU_Optimized, RandomWalkMH_GPU_Optimized, geometric_beta_ladder
+    from algorithms.sharding import allreduce_summary
+    from target_distributions import RoughCarpetDistributionTorch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    dim, T, C = args.dim, (1 if args.workload == "rwm" else args.temps), args.chains
+    target = RoughCarpetDistributionTorch(dim, device=dev, mode_centers=[-15.0, 0.0, 15.0])
+    burn = 0
+    offset = rank * C  # weak scaling: global ladder ids [rank*C, (rank+1)*C)
+    if args.workload == "rwm":
+        alg = RandomWalkMH_GPU_Optimized(dim, 2.38**2 / dim, target, burn_in=burn, device=dev, num_chains=C, seed=42,
+                                         chain_offset=offset)
+        alg._ensure_started()
+    else:
+        alg = ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target, beta_ladder=geometric_beta_ladder(T),
+                                                 swap_every=args.swap_every, burn_in=burn, device=dev, num_replicas=C,
+                                                 seed=42, chain_offset=offset, trace="none", swap_order=args.swap_order)
+        alg._ensure_started()
+    run = alg._run
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        run.advance(args.inner)
+    torch.cuda.synchronize()
+    barrier()
+    # timed region: exactly K launches; one HIP event pair per launch on the launch stream (the current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        run.advance(args.inner)
+        b.record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+    summary = allreduce_summary(run.summary(), dev)  # the only collective: whole-job acceptance / ESJD
+    units_per_launch = C * T * args.inner            # per GPU
+    value = world * units_per_launch * args.steps / elapsed
+    alg_bytes = (8 * dim + 24) * units_per_launch
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            with open(tfile) as f:
+                tj = json.load(f)
+            key = f"{args.workload}_d{dim}_T{T}_C{C}_inner{args.inner}"
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "chain-MH-steps/sec", "value": value, "unit": "chain-MH-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": ("BASELINE configs[2]: PT-RWM HIP, RoughCarpet dim=30 modes[-15,0,15], Normal proposal "
+                             "2.38^2/dim, 32 geometric temps 1->0.01, swap_every=10, 65536 ladders per GPU"
+                             if args.workload == "pt" else
+                             "BASELINE configs[1]: RWM HIP, RoughCarpet dim=30, Normal proposal, 65536 chains per GPU"),
+                "dim": dim, "temps": T, "ladders_per_gpu": C, "mh_steps_per_launch": args.inner,
+                "swap_every": args.swap_every, "swap_mode": "exchange", "swap_order": args.swap_order,
+                "rng": "Philox4x32-10 in-kernel", "sharding": f"{world} x {C} independent ladders, no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "kernel": "ptrwm_step_kernel<RoughCarpet<30>, NormalProposal<30>, 30, exact, production>",
+                "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "algorithmic bytes = (8*dim+24) B per chain-MH-step (streaming formulation); the fused kernel "
+                        "keeps state in registers for the whole launch, so real HBM traffic is ~1/inner of that and "
+                        "the kernel is VALU-issue bound, see DESIGN.md",
+            },
+            "summary": {
+                "acceptance_rate_cold": float(summary["acceptance_rate"][0]),
+                "acceptance_rate_hot": float(summary["acceptance_rate"][-1]),
+                "esjd_cold": float(summary["esjd"][0]),
+                "swap_acceptance_rate": summary["swap_acceptance_rate"],
+                "replicas": summary["n_replicas"],
+            },
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(dim, T, args.cpu_seconds)
+            out["cpu_baseline"]["c_oracle_chain_steps_per_s_1core"] = c_oracle_rate(dim, T, args.swap_every)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

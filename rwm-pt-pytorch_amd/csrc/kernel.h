@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     }
 
     const float u_acc = Proposal::propose(y, x, fresh_dim<EXACT>(D0), tscale, a.pp, rc, ext_raw, ext_u);
-    const float lp_new = Target::logp(y, fresh_dim<EXACT>(D0), a.tp);
+    const float lp_new = Target::template logp<false>(y, fresh_dim<EXACT>(D0), a.tp);
     const int D = fresh_dim<EXACT>(D0);
 
     // ultra_fused_mcmc_step_basic / ultra_fused_parallel_mcmc_step:
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(kBlockThreads) ptrwm_logdensity_kernel(const f
   const float *__restrict__ xp = x + i * D;
 #pragma unroll
   for (int d = 0; d < DP; ++d) y[d] = (d < D) ? xp[d] : 0.0f;
-  out[i] = Target::logp(y, D, tp);
+  out[i] = Target::template logp<true>(y, D, tp);
 }
 
 // ---- standalone proposal kernel (unit parity of the three samplers) ----

@@ -30,7 +30,10 @@ constexpr float kNegInf = -__builtin_huge_valf();
 template <int DP>
 struct RoughCarpet {
   static constexpr int kKind = PTRWM_TARGET_ROUGH_CARPET;
-  template <bool SCALED>
+  // STRICT: all three exponents can be -inf only for |x| > ~1e19; torch.logsumexp then returns -inf where the
+  // plain max-shift gives inf - inf = NaN.  The MH loop rejects either value, so only the stand-alone
+  // log-density kernel pays for the guarded shift (one v_max per dimension).
+  template <bool SCALED, bool STRICT>
   __device__ __forceinline__ static float logp_impl(const float (&y)[DP], int D, const TParams &tp) {
     const float m0 = tp.p[0], m1 = tp.p[1], m2 = tp.p[2];
     // log2-domain log-weights
@@ -49,7 +52,8 @@ struct RoughCarpet {
         const float mx = __builtin_fmaxf(__builtin_fmaxf(a0, a1), a2);
         const float mn = __builtin_fminf(__builtin_fminf(a0, a1), a2);
         const float md = __builtin_amdgcn_fmed3f(a0, a1, a2);
-        const float s = 1.0f + hw_exp2(md - mx) + hw_exp2(mn - mx);
+        const float sh = STRICT ? __builtin_fmaxf(mx, -3.0e38f) : mx;
+        const float s = 1.0f + hw_exp2(md - sh) + hw_exp2(mn - sh);
         sum_mx += mx;
         prod *= s;
       }
@@ -63,9 +67,10 @@ struct RoughCarpet {
     // p[6] = log_jacobian, p[7] = -dim * log(sqrt(2 pi)) folded on the host
     return fmaf(sum_mx + lg, kLn2, tp.p[7]) + tp.p[6];
   }
+  template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
     // one wave-uniform branch per evaluation instead of one per dimension
-    return tp.vec0 != nullptr ? logp_impl<true>(y, D, tp) : logp_impl<false>(y, D, tp);
+    return tp.vec0 != nullptr ? logp_impl<true, STRICT>(y, D, tp) : logp_impl<false, STRICT>(y, D, tp);
   }
 };
 
@@ -96,9 +101,11 @@ struct ThreeMixture {
     const float a1 = fmaf(-0.5f, q1, tp.p[1]);
     const float a2 = fmaf(-0.5f, q2, tp.p[2]);
     const float mx = __builtin_fmaxf(__builtin_fmaxf(a0, a1), a2);
-    const float s = hw_exp((a0 - mx)) + hw_exp((a1 - mx)) + hw_exp((a2 - mx));
+    const float sh = __builtin_fmaxf(mx, -3.0e38f);  // all components -inf -> -inf like torch.logsumexp, not NaN
+    const float s = hw_exp((a0 - sh)) + hw_exp((a1 - sh)) + hw_exp((a2 - sh));
     return mx + hw_ln(s);
   }
+  template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
     return tp.vec1 != nullptr ? logp_impl<true>(y, D, tp) : logp_impl<false>(y, D, tp);
   }
@@ -109,6 +116,7 @@ struct ThreeMixture {
 template <int DP>
 struct FullRosenbrock {
   static constexpr int kKind = PTRWM_TARGET_FULL_ROSENBROCK;
+  template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
     const float a = tp.p[0], b = tp.p[1];
     float s1 = 0.0f, s2 = 0.0f;
@@ -131,6 +139,7 @@ struct FullRosenbrock {
 template <int DP>
 struct EvenRosenbrock {
   static constexpr int kKind = PTRWM_TARGET_EVEN_ROSENBROCK;
+  template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
     const float a = tp.p[0], b = tp.p[1];
     float s1 = 0.0f, s2 = 0.0f;
@@ -155,6 +164,7 @@ struct EvenRosenbrock {
 template <int DP>
 struct HybridRosenbrock {
   static constexpr int kKind = PTRWM_TARGET_HYBRID_ROSENBROCK;
+  template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
     const float a = tp.p[0], b = tp.p[1], mu = tp.p[2];
     const float c0 = y[0] - mu;
@@ -178,6 +188,7 @@ struct HybridRosenbrock {
 template <int DP>
 struct IIDGamma {
   static constexpr int kKind = PTRWM_TARGET_IID_GAMMA;
+  template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
     const float km1 = (tp.p[0] - 1.0f) * kLn2;
     const float inv_theta = 1.0f / tp.p[1];
@@ -201,6 +212,7 @@ struct IIDGamma {
 template <int DP>
 struct IIDBeta {
   static constexpr int kKind = PTRWM_TARGET_IID_BETA;
+  template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
     const float am1 = (tp.p[0] - 1.0f) * kLn2;
     const float bm1 = (tp.p[1] - 1.0f) * kLn2;

@@ -1,0 +1,128 @@
+"""The C-ABI shared library loads without a GPU and exports exactly what include/ptrwm.h declares; the ctypes
+mirrors of its structs have the C layout; argument validation runs before any HIP call.  CPU only."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ptrwm.h")
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import ptrwm_hip
+
+    if not os.path.exists(ptrwm_hip.LIB_PATH):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return ptrwm_hip
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptrwm_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_functions_are_all_exported_and_bound(engine):
+    lib = engine.load_library()
+    names = declared_functions()
+    assert len(names) >= 8
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ptrwm.h but not exported"
+    assert sorted(engine.SYMBOLS) == names  # the Python binding covers the whole header, nothing else
+    assert lib.ptrwm_abi_version() == engine.ABI_VERSION
+
+
+def test_struct_layouts_match_the_c_header(engine, tmp_path):
+    """Compile a probe with gcc against the real header and compare sizeof/offsetof with the ctypes mirrors
+    (both the product binding and the oracle's)."""
+    from oracle import oracle as O
+
+    fields = {
+        "ptrwm_target_desc": ["kind", "dim", "p", "ip", "vec0", "vec1"],
+        "ptrwm_proposal_desc": ["kind", "inv_dim", "temp_scale", "dim_scale"],
+        "ptrwm_run_args": [f[0] for f in engine.RunArgs._fields_],
+    }
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
+    for s, fs in fields.items():
+        lines.append(f'printf("{s} %zu\\n", sizeof({s}));')
+        for f in fs:
+            lines.append(f'printf("{s}.{f} %zu\\n", offsetof({s}, {f}));')
+    lines.append("return 0;}")
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-o", str(exe), str(src)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for mod in (engine, O):
+        for cname, cls in (("ptrwm_target_desc", mod.TargetDesc), ("ptrwm_proposal_desc", mod.ProposalDesc),
+                           ("ptrwm_run_args", mod.RunArgs)):
+            assert C.sizeof(cls) == int(got[cname])
+            for f in fields[cname]:
+                assert getattr(cls, f).offset == int(got[f"{cname}.{f}"]), (mod.__name__, cname, f)
+    hdr = open(HEADER).read()
+    assert int(re.search(r"#define PTRWM_MAX_DIM (\d+)", hdr).group(1)) == engine.MAX_DIM
+    assert int(re.search(r"#define PTRWM_MAX_TEMPS (\d+)", hdr).group(1)) == engine.MAX_TEMPS
+
+
+def test_validation_needs_no_gpu(engine):
+    """Every error path returns before the first HIP call, so it can be exercised here."""
+    lib = engine.load_library()
+    assert engine.strerror(0) == "ok" and "NULL" in engine.strerror(-1)
+    assert engine.ext_raw_per_step(engine.PROPOSAL_NORMAL, 30) == 30
+    assert engine.ext_raw_per_step(engine.PROPOSAL_UNIFORM_RADIUS, 50) == 51
+    with pytest.raises(engine.PTRWMError):
+        engine.ext_raw_per_step(7, 3)
+    # variants: every dim 1..104, every target and proposal; nothing beyond
+    for t in range(7):
+        for p in range(3):
+            assert all(engine.has_variant(t, p, d) for d in (1, 2, 3, 5, 30, 31, 50, 64, 65, 100, 104))
+            assert not engine.has_variant(t, p, 105) and not engine.has_variant(t, p, 0)
+    assert not engine.has_variant(7, 0, 30) and not engine.has_variant(0, 3, 30)
+
+    td, pd, ra = engine.TargetDesc(), engine.ProposalDesc(), engine.RunArgs()
+    assert lib.ptrwm_run(None, None, None, None) == -1
+    td.kind, td.dim = 0, 30
+    ra.struct_size = 4
+    assert lib.ptrwm_run(C.byref(td), C.byref(pd), C.byref(ra), None) == -6  # struct size / ABI mismatch
+    ra.struct_size = C.sizeof(engine.RunArgs)
+    ra.n_temps, ra.swap_every = 65, 1
+    assert lib.ptrwm_run(C.byref(td), C.byref(pd), C.byref(ra), None) == -3  # too many temperatures
+    ra.n_temps, ra.swap_every = 4, 0
+    assert lib.ptrwm_run(C.byref(td), C.byref(pd), C.byref(ra), None) == -5
+    ra.swap_every = 1
+    assert lib.ptrwm_run(C.byref(td), C.byref(pd), C.byref(ra), None) == -1  # state pointers missing
+    td.dim = 105
+    assert lib.ptrwm_run(C.byref(td), C.byref(pd), C.byref(ra), None) == -2
+    td.kind, td.dim = 9, 30
+    assert lib.ptrwm_logdensity(C.byref(td), None, None, 1, None) == -4
+    td.kind, td.dim = 3, 31  # EvenRosenbrock needs an even dim
+    assert lib.ptrwm_logdensity(C.byref(td), None, None, 1, None) == -2
+    td.kind, td.dim, td.ip[0], td.ip[1] = 4, 12, 3, 5  # Hybrid: dim must be 1 + n2 (n1 - 1) = 11
+    assert lib.ptrwm_logdensity(C.byref(td), None, None, 1, None) == -2
+    td.dim = 11
+    assert lib.ptrwm_logdensity(C.byref(td), None, None, 0, None) == 0  # empty batch: ok, nothing launched
+
+
+def test_product_refuses_to_run_without_its_library_or_a_gpu(engine, tmp_path):
+    import torch
+
+    with pytest.raises(RuntimeError, match="not found"):
+        engine.load_library(str(tmp_path / "nope.so"))
+    t = engine.Target(engine.TARGET_ROUGH_CARPET, 3, p=(-1, 0, 1, -1, -1, -1, 0))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        engine.logdensity(t, torch.zeros(2, 3))
+    # nothing in the product package imports the oracle
+    pkg = os.path.join(ROOT, "rwm-pt-pytorch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f
