@@ -16,7 +16,8 @@ from typing import Optional
 import torch  # noqa: F401  (must be imported first: loads the HIP runtime the library binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libptrwm_hip.so")
+# PTRWM_LIB: alternative build of the same library (A/B tuning experiments)
+LIB_PATH = os.environ.get("PTRWM_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libptrwm_hip.so")
 
 ABI_VERSION = 1
 MAX_DIM = 104

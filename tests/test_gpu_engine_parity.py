@@ -170,7 +170,7 @@ def test_philox_proposals_match_oracle_and_moments(device, kind, dim):
             r = np.linalg.norm(got[:, t], axis=1)
             R = 1.3 / np.sqrt(b)
             assert r.max() <= R * (1 + 1e-5)
-            assert np.mean(r**dim) / R**dim == pytest.approx(0.5, abs=0.02)  # (r/R)^d is U(0,1)
+            assert np.mean((r.astype(np.float64) / R) ** dim) == pytest.approx(0.5, abs=0.02)  # (r/R)^d is U(0,1)
         assert abs(got[:, t].mean()) < 4 * np.sqrt(got[:, t].var() / (n * dim)) + 1e-3
 
 
@@ -327,7 +327,10 @@ def test_external_randoms_vs_oracle(device, tkey, pkind, T, Cn, pkw, mode, order
         assert np.array_equal(got["trace"][:upto], want["trace"][:upto])
     else:
         np.testing.assert_allclose(got["trace"][:upto], want["trace"][:upto], rtol=1e-4, atol=1e-5)
-    logp_close(got["trace_logp"][:upto], want["trace_logp"][:upto], extra_abs=3e-4)
+    # carried log-densities are those of the carried states (checked at the kernel's own states, so that the
+    # <= 2 ulp increment differences of Laplace / UniformRadius cannot leak into this tolerance)
+    own = O.logdensity(spec.oracle(), got["trace"].reshape(-1, spec.dim), "f64").reshape(got["trace_logp"].shape)
+    logp_close(got["trace_logp"], own, extra_abs=3e-4)
     if first is None:
         for k in ("n_accept", "swap_accept", "last_swap_ordinal"):
             assert np.array_equal(got[k], want[k]), k
