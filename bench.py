@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--dim", type=int, default=30)
     ap.add_argument("--swap-every", type=int, default=10)
     ap.add_argument("--swap-order", default="sequential", choices=["sequential", "even_odd"])
-    ap.add_argument("--workload", default="pt", choices=["pt", "rwm"], help="rwm = configs[1] (one temperature)")
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "pt", "rwm"],
+                    help="BASELINE.json configs[1..4] (cfg3 = configs[2], the headline); pt = cfg3, rwm = cfg2")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
     return ap.parse_args()
 
@@ -122,19 +123,47 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    dim, T, C = args.dim, (1 if args.workload == "rwm" else args.temps), args.chains
-    target = RoughCarpetDistributionTorch(dim, device=dev, mode_centers=[-15.0, 0.0, 15.0])
+    from proposal_distributions import LaplaceProposal, UniformRadiusProposal
+    from target_distributions import EvenRosenbrockTorch, ThreeMixtureDistributionTorch
+
+    wl = {"pt": "cfg3", "rwm": "cfg2"}.get(args.workload, args.workload)
+    dim, T, C = args.dim, args.temps, args.chains
     burn = 0
+    proposal = None
+    np_seed = 1234  # EvenRosenbrock starts at 1e-8 N(0,1) drawn from the global NumPy RNG: fix it
+    import numpy as np
+
+    np.random.seed(np_seed)
+    if wl == "cfg2":
+        T = 1
+        target = RoughCarpetDistributionTorch(dim, device=dev, mode_centers=[-15.0, 0.0, 15.0])
+        desc = "BASELINE configs[1]: RWM HIP, RoughCarpet dim=30 modes[-15,0,15], Normal proposal 2.38^2/dim, 65536 chains per GPU"
+    elif wl == "cfg3":
+        target = RoughCarpetDistributionTorch(dim, device=dev, mode_centers=[-15.0, 0.0, 15.0])
+        desc = ("BASELINE configs[2]: PT-RWM HIP, RoughCarpet dim=30 modes[-15,0,15], Normal proposal 2.38^2/dim, "
+                "32 geometric temps 1->0.01, swap_every=10, 65536 ladders per GPU")
+    elif wl == "cfg4":
+        target = EvenRosenbrockTorch(dim, device=dev)
+        proposal = LaplaceProposal(dim, torch.full((dim,), 0.004), 1.0, dev, torch.float32)
+        desc = ("BASELINE configs[3]: PT-RWM HIP, EvenRosenbrock dim=30, Laplace proposal base variance 0.004 per dim, 32 geometric "
+                "temps, swap_every=10, 65536 ladders per GPU (524288 over 8), no collectives")
+    else:
+        dim, T = 50, 64
+        C = args.chains * 2 if args.chains == 65536 else args.chains  # 131072 ladders per GPU (1048576 over 8)
+        target = ThreeMixtureDistributionTorch(dim, device=dev)
+        proposal = UniformRadiusProposal(dim, 2.4, 1.0, dev, torch.float32)
+        desc = ("BASELINE configs[4]: PT-RWM HIP, ThreeMixture dim=50 (class defaults), UniformRadius base_radius 2.4, "
+                "64 geometric temps, swap_every=10, 131072 ladders per GPU (1048576 over 8), summary all-reduce")
     offset = rank * C  # weak scaling: global ladder ids [rank*C, (rank+1)*C)
-    if args.workload == "rwm":
+    if wl == "cfg2":
         alg = RandomWalkMH_GPU_Optimized(dim, 2.38**2 / dim, target, burn_in=burn, device=dev, num_chains=C, seed=42,
                                          chain_offset=offset)
-        alg._ensure_started()
     else:
         alg = ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target, beta_ladder=geometric_beta_ladder(T),
                                                  swap_every=args.swap_every, burn_in=burn, device=dev, num_replicas=C,
-                                                 seed=42, chain_offset=offset, trace="none", swap_order=args.swap_order)
-        alg._ensure_started()
+                                                 seed=42, chain_offset=offset, trace="none", swap_order=args.swap_order,
+                                                 proposal_distribution=proposal)
+    alg._ensure_started()
     run = alg._run
 
     def barrier():
@@ -173,17 +202,14 @@ def main():
         if os.path.exists(tfile):
             with open(tfile) as f:
                 tj = json.load(f)
-            key = f"{args.workload}_d{dim}_T{T}_C{C}_inner{args.inner}"
+            key = f"{'rwm' if T == 1 else 'pt'}_d{dim}_T{T}_C{C}_inner{args.inner}" if wl in ("cfg2", "cfg3") else wl
             traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "chain-MH-steps/sec", "value": value, "unit": "chain-MH-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": ("BASELINE configs[2]: PT-RWM HIP, RoughCarpet dim=30 modes[-15,0,15], Normal proposal "
-                             "2.38^2/dim, 32 geometric temps 1->0.01, swap_every=10, 65536 ladders per GPU"
-                             if args.workload == "pt" else
-                             "BASELINE configs[1]: RWM HIP, RoughCarpet dim=30, Normal proposal, 65536 chains per GPU"),
+                "workload": desc,
                 "dim": dim, "temps": T, "ladders_per_gpu": C, "mh_steps_per_launch": args.inner,
                 "swap_every": args.swap_every, "swap_mode": "exchange", "swap_order": args.swap_order,
                 "rng": "Philox4x32-10 in-kernel", "sharding": f"{world} x {C} independent ladders, no data-path collective",
@@ -191,7 +217,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "kernel": "ptrwm_step_kernel<RoughCarpet<30>, NormalProposal<30>, 30, exact, production>",
+                "kernel": f"ptrwm_step_kernel<{type(target).__name__}, {alg.proposal_dist.get_name()}, dim {dim}, production>",
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "algorithmic bytes = (8*dim+24) B per chain-MH-step (streaming formulation); the fused kernel "
                         "keeps state in registers for the whole launch, so real HBM traffic is ~1/inner of that and "

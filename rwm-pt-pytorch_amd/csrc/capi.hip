@@ -5,9 +5,9 @@
 
 namespace ptrwm {
 
-static const TargetVariants *target_variants(int kind) {
+static const TargetVariants *target_variants(int kind, bool two_term = false) {
   switch (kind) {
-    case PTRWM_TARGET_ROUGH_CARPET: return &rough_carpet_variants();
+    case PTRWM_TARGET_ROUGH_CARPET: return two_term ? &rough_carpet2_variants() : &rough_carpet_variants();
     case PTRWM_TARGET_THREE_MIXTURE: return &three_mixture_variants();
     case PTRWM_TARGET_FULL_ROSENBROCK: return &full_rosenbrock_variants();
     case PTRWM_TARGET_EVEN_ROSENBROCK: return &even_rosenbrock_variants();
@@ -42,6 +42,32 @@ static int check_target(const ptrwm_target_desc *t) {
       break;
   }
   return PTRWM_OK;
+}
+
+// RoughCarpet: is the smallest of the three per-dimension mixture terms always < 2^-26 of the largest?
+// g(x) = max_k a_k(x) - min_k a_k(x) in log2 units, a_k = -0.5 log2(e) (x - m_k)^2 + log2 w_k.  Outside
+// [min m - 1, max m + 1] g grows linearly, so a grid over that interval bounds it.
+static bool rough_carpet_two_term(const float *p) {
+  const double l2e = 1.4426950408889634;
+  double lo = p[0], hi = p[0];
+  for (int k = 1; k < 3; ++k) {
+    lo = p[k] < lo ? p[k] : lo;
+    hi = p[k] > hi ? p[k] : hi;
+  }
+  lo -= 1.0;
+  hi += 1.0;
+  const int n = 40000;
+  for (int i = 0; i <= n; ++i) {
+    const double x = lo + (hi - lo) * i / n;
+    double amax = -1e300, amin = 1e300;
+    for (int k = 0; k < 3; ++k) {
+      const double a = (-0.5 * (x - p[k]) * (x - p[k]) + p[3 + k]) * l2e;
+      amax = a > amax ? a : amax;
+      amin = a < amin ? a : amin;
+    }
+    if (!(amax - amin > 27.0)) return false;  // also false for NaN parameters
+  }
+  return true;
 }
 
 static TParams make_tparams(const ptrwm_target_desc *t) {
@@ -152,7 +178,8 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
 
   const int dpi = width_index_for_dim(target->dim);
   if (dpi < 0) return PTRWM_E_DIM;
-  const RunLaunchFn fn = target_variants(target->kind)->run[proposal->kind][dpi];
+  const bool two_term = target->kind == PTRWM_TARGET_ROUGH_CARPET && rough_carpet_two_term(target->p);
+  const RunLaunchFn fn = target_variants(target->kind, two_term)->run[proposal->kind][dpi];
   if (fn == nullptr) return PTRWM_E_NOVARIANT;
 
   const long long se = args->swap_every;

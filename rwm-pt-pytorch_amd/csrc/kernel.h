@@ -80,11 +80,13 @@ __device__ __forceinline__ int fresh_dim(int d0) {
 
 // Register budget: the replica's x[DP] and y[DP] plus ~30 temporaries must stay in VGPRs.  Without a
 // bound hipcc hoists every Philox block of a step ahead of its consumers and lands far above that.
-#ifdef PTRWM_WAVES_OVERRIDE  // tuning experiments only
-constexpr int min_waves_per_simd(int dp) { return dp <= 44 ? PTRWM_WAVES_OVERRIDE : (dp <= 64 ? 3 : 1); }
-#else
-constexpr int min_waves_per_simd(int dp) { return dp <= 44 ? 4 : (dp <= 64 ? 3 : 1); }
+#ifndef PTRWM_WAVES_SMALL  // tuning knobs (profiles/r01_bench_variants.txt: 4 beats 3, 5 and 6 at dim 30)
+#define PTRWM_WAVES_SMALL 4
 #endif
+#ifndef PTRWM_WAVES_MID
+#define PTRWM_WAVES_MID 2
+#endif
+constexpr int min_waves_per_simd(int dp) { return dp <= 44 ? PTRWM_WAVES_SMALL : (dp <= 64 ? PTRWM_WAVES_MID : 1); }
 
 template <class Target, class Proposal, int DP, bool EXACT, bool FULL>
 __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_step_kernel(const KArgs a) {

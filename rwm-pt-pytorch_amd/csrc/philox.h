@@ -30,19 +30,42 @@ constexpr uint32_t kPhiloxW1 = 0xBB67AE85u;
 constexpr uint32_t kStreamMH = 0u;
 constexpr uint32_t kStreamSwap = 1u;
 
+// 32x32 -> 64 multiply by a constant as two full-rate instructions.  hipcc would fuse the pair into one
+// v_mad_u64_u32, which measures 2.8x the issue cost of a full-rate op on gfx950 against 1.0 each for
+// v_mul_hi_u32 / v_mul_lo_u32 (profiles/r01_ubench_valu_costs.txt); the asm keeps them apart.
+__device__ __forceinline__ void mul_hilo(uint32_t m, uint32_t x, uint32_t &hi, uint32_t &lo) {
+#ifdef PTRWM_PHILOX_MAD64
+  const uint64_t p = (uint64_t)m * x;
+  hi = (uint32_t)(p >> 32);
+  lo = (uint32_t)p;
+#else
+  asm("v_mul_hi_u32 %0, %1, %2" : "=v"(hi) : "s"(m), "v"(x));
+  asm("v_mul_lo_u32 %0, %1, %2" : "=v"(lo) : "s"(m), "v"(x));
+#endif
+}
+
 // One Philox4x32-10 block.  The key schedule is wave-uniform (seed only), so the
 // ten round keys live in SGPRs; per round the VALU work is two 32x32->64
-// multiplies (v_mad_u64_u32) and two three-way xors.
+// multiplies and two three-way xors.
 __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)kPhiloxM0 * c0;
-    const uint64_t p1 = (uint64_t)kPhiloxM1 * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    c1 = (uint32_t)p1;
-    c3 = (uint32_t)p0;
+    uint32_t hi0, lo0, hi1, lo1;
+    if (r == 0) {
+      // c0 of the first round is the block index: wave-uniform in the step kernel, so left to the
+      // compiler this product is two SALU multiplies
+      const uint64_t p0 = (uint64_t)kPhiloxM0 * c0;
+      hi0 = (uint32_t)(p0 >> 32);
+      lo0 = (uint32_t)p0;
+    } else {
+      mul_hilo(kPhiloxM0, c0, hi0, lo0);
+    }
+    mul_hilo(kPhiloxM1, c2, hi1, lo1);
+    const uint32_t n0 = hi1 ^ c1 ^ k0;
+    const uint32_t n2 = hi0 ^ c3 ^ k1;
+    c1 = lo1;
+    c3 = lo0;
     c0 = n0;
     c2 = n2;
     k0 += kPhiloxW0;
@@ -68,14 +91,19 @@ __device__ __forceinline__ float hw_sqrt(float x) { return __builtin_amdgcn_sqrt
 __device__ __forceinline__ float hw_exp(float x) { return hw_exp2(x * kLog2e); }
 __device__ __forceinline__ float hw_ln(float x) { return hw_log2(x) * kLn2; }
 
-// Box-Muller on two raw words.  v_sin_f32 / v_cos_f32 take their argument in
-// revolutions, so sin(2*pi*u2) is one instruction.
+// Box-Muller on two raw words (ra -> radius, rb -> angle).
+//   radius: u1 = ((ra >> 8) + 1) * 2^-24 in (0, 1], r^2 = -2 ln u1.  (Folding the 2^-24 into an fma behind the
+//           log saves a multiply but cancels near u1 = 1 and costs 1e-5 sigma of absolute accuracy: not done.)
+//   angle:  v_sin_f32 / v_cos_f32 take their argument in revolutions and are periodic, so the low 23 bits of rb
+//           dropped into the mantissa of a float in [1, 2) ARE the angle (one v_and_or_b32, no cvt, no scaling).
+__device__ __forceinline__ float bm_radius_sq(uint32_t ra) { return (-2.0f * kLn2) * hw_log2(u01_open0(ra)); }
+__device__ __forceinline__ float bm_turns(uint32_t rb) { return __uint_as_float((rb & 0x007FFFFFu) | 0x3F800000u); }
+
 __device__ __forceinline__ void box_muller(uint32_t ra, uint32_t rb, float &z0, float &z1) {
-  const float u1 = u01_open0(ra);
-  const float u2 = u01(rb);
-  const float rad = hw_sqrt((-2.0f * kLn2) * hw_log2(u1));
-  z0 = rad * __builtin_amdgcn_sinf(u2);
-  z1 = rad * __builtin_amdgcn_cosf(u2);
+  const float rad = hw_sqrt(bm_radius_sq(ra));
+  const float ang = bm_turns(rb);
+  z0 = rad * __builtin_amdgcn_sinf(ang);
+  z1 = rad * __builtin_amdgcn_cosf(ang);
 }
 
 // Scheduling fence.  Every loop over the dim-vector is fully unrolled; without fences hipcc's

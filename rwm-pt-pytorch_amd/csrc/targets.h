@@ -27,13 +27,17 @@ constexpr float kNegInf = -__builtin_huge_valf();
 // modes), sorted with max3/med3/min3 so only two v_exp_f32 are needed, and the
 // log of the 3-term sum is deferred: sum_d log2(s_d) = log2(prod_d s_d) with
 // s_d in [1,3], one v_log_f32 per 32 dimensions instead of one per dimension.
-template <int DP>
-struct RoughCarpet {
+template <int DP, bool TWO_TERM>
+struct RoughCarpetT {
   static constexpr int kKind = PTRWM_TARGET_ROUGH_CARPET;
   // STRICT: all three exponents can be -inf only for |x| > ~1e19; torch.logsumexp then returns -inf where the
   // plain max-shift gives inf - inf = NaN.  The MH loop rejects either value, so only the stand-alone
   // log-density kernel pays for the guarded shift (one v_max per dimension).
-  template <bool SCALED, bool STRICT>
+  // TWO (kernel variant RoughCarpet2, chosen by capi.hip): the host has proved (rough_carpet_two_term) that for
+  // every x the smallest of the three terms is below 2^-26 of the largest: adding it to a sum >= 1 cannot change
+  // the fp32 result, so it (one v_exp_f32, min3, a subtract and an add per dimension) is dropped with
+  // bit-identical output.  True for the +-15 modes of the benchmark target, false e.g. for modes +-4.
+  template <bool SCALED, bool STRICT, bool TWO>
   __device__ __forceinline__ static float logp_impl(const float (&y)[DP], int D, const TParams &tp) {
     const float m0 = tp.p[0], m1 = tp.p[1], m2 = tp.p[2];
     // log2-domain log-weights
@@ -50,10 +54,13 @@ struct RoughCarpet {
         const float a1 = fmaf(d1 * d1, nh, w1);
         const float a2 = fmaf(d2 * d2, nh, w2);
         const float mx = __builtin_fmaxf(__builtin_fmaxf(a0, a1), a2);
-        const float mn = __builtin_fminf(__builtin_fminf(a0, a1), a2);
         const float md = __builtin_amdgcn_fmed3f(a0, a1, a2);
         const float sh = STRICT ? __builtin_fmaxf(mx, -3.0e38f) : mx;
-        const float s = 1.0f + hw_exp2(md - sh) + hw_exp2(mn - sh);
+        float s = 1.0f + hw_exp2(md - sh);
+        if constexpr (!TWO) {
+          const float mn = __builtin_fminf(__builtin_fminf(a0, a1), a2);
+          s += hw_exp2(mn - sh);
+        }
         sum_mx += mx;
         prod *= s;
       }
@@ -69,10 +76,15 @@ struct RoughCarpet {
   }
   template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
-    // one wave-uniform branch per evaluation instead of one per dimension
-    return tp.vec0 != nullptr ? logp_impl<true, STRICT>(y, D, tp) : logp_impl<false, STRICT>(y, D, tp);
+    // wave-uniform branches per evaluation instead of per dimension
+    constexpr bool two = TWO_TERM && !STRICT;
+    return tp.vec0 != nullptr ? logp_impl<true, STRICT, two>(y, D, tp) : logp_impl<false, STRICT, two>(y, D, tp);
   }
 };
+template <int DP>
+using RoughCarpet = RoughCarpetT<DP, false>;
+template <int DP>
+using RoughCarpet2 = RoughCarpetT<DP, true>;
 
 // ThreeMixtureDistributionTorch.log_density, multimodal_torch.py:173-242.  cov_invs
 // is always the identity (:87-98) so the [B,D]x[D,D] matmul at :234 is skipped.

@@ -81,6 +81,7 @@ hipError_t launch_logp(const float *x, float *out, long long n, int D, const TPa
   }
 
 const TargetVariants &rough_carpet_variants();
+const TargetVariants &rough_carpet2_variants();  // two-term specialisation, see targets.h
 const TargetVariants &three_mixture_variants();
 const TargetVariants &full_rosenbrock_variants();
 const TargetVariants &even_rosenbrock_variants();
