@@ -117,11 +117,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU over RCCL (backend "nccl").  PTRWM_BENCH_BACKEND=gloo rehearses the multi-process path on a
+    # box with fewer GPUs than ranks (ranks then share devices; collectives go through host tensors).
+    backend = os.environ.get("PTRWM_BENCH_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from proposal_distributions import LaplaceProposal, UniformRadiusProposal
     from target_distributions import EvenRosenbrockTorch, ThreeMixtureDistributionTorch
@@ -185,12 +193,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
-    summary = allreduce_summary(run.summary(), dev)  # the only collective: whole-job acceptance / ESJD
+    summary = allreduce_summary(run.summary(), coll_dev)  # the only collective: whole-job acceptance / ESJD
     units_per_launch = C * T * args.inner            # per GPU
     value = world * units_per_launch * args.steps / elapsed
     alg_bytes = (8 * dim + 24) * units_per_launch

@@ -166,6 +166,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
     return PTRWM_E_ARG;
   if (args->swap_mode != PTRWM_SWAP_EXCHANGE && args->swap_mode != PTRWM_SWAP_REFERENCE_COPY) return PTRWM_E_ARG;
   if (args->swap_order != PTRWM_ORDER_SEQUENTIAL && args->swap_order != PTRWM_ORDER_EVEN_ODD) return PTRWM_E_ARG;
+  if (args->n_chains == 0 || args->n_steps == 0) return PTRWM_OK;  // empty batch: nothing to touch
   if (args->state == nullptr || args->logp == nullptr || args->beta == nullptr || proposal->temp_scale == nullptr)
     return PTRWM_E_NULL;
   if (proposal->kind == PTRWM_PROPOSAL_LAPLACE && proposal->dim_scale == nullptr) return PTRWM_E_NULL;
@@ -174,7 +175,6 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   if (args->trace != nullptr && (args->trace_chains < 1 || args->trace_temps < 1 || args->trace_row0 < 0 ||
                                  args->trace_temps > args->n_temps || args->trace_chains > args->n_chains))
     return PTRWM_E_ARG;
-  if (args->n_chains == 0 || args->n_steps == 0) return PTRWM_OK;
 
   const int dpi = width_index_for_dim(target->dim);
   if (dpi < 0) return PTRWM_E_DIM;

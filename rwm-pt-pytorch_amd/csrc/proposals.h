@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t pick(const u32x4 &r, int lane4) {
 template <int DP>
 __device__ __forceinline__ void philox_normals(float (&z)[DP], int D, const RngCtx &rc, int w_a,
                                                float &ua, float &ub) {
-  constexpr int NB = DP / 4 + 1;
+  constexpr int NB = (2 * ((DP + 1) / 2)) / 4 + 1;  // blocks up to the one holding word 2*ceil(DP/2)
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
     if (4 * c <= w_a + 1) {
@@ -73,7 +73,7 @@ __device__ __forceinline__ void philox_normals(float (&z)[DP], int D, const RngC
 template <int DP>
 __device__ __forceinline__ float philox_normal_step(float (&y)[DP], const float (&x)[DP], int D, float tscale,
                                                     const RngCtx &rc) {
-  constexpr int NB = DP / 4 + 1;
+  constexpr int NB = (2 * ((DP + 1) / 2)) / 4 + 1;  // blocks up to the one holding word 2*ceil(DP/2)
   const int w_a = 2 * ((D + 1) >> 1);
   float u_acc = 0.0f;
 #pragma unroll

@@ -98,6 +98,8 @@ def test_validation_needs_no_gpu(engine):
     ra.n_temps, ra.swap_every = 4, 0
     assert lib.ptrwm_run(C.byref(td), C.byref(pd), C.byref(ra), None) == -5
     ra.swap_every = 1
+    assert lib.ptrwm_run(C.byref(td), C.byref(pd), C.byref(ra), None) == 0  # no chains, no steps: a no-op
+    ra.n_chains, ra.n_steps = 4, 10
     assert lib.ptrwm_run(C.byref(td), C.byref(pd), C.byref(ra), None) == -1  # state pointers missing
     td.dim = 105
     assert lib.ptrwm_run(C.byref(td), C.byref(pd), C.byref(ra), None) == -2

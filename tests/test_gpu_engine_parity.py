@@ -406,3 +406,143 @@ def test_argument_validation_through_the_abi(device):
     E.run(spec.engine(device), prop.engine(device), state=st, logp=lp, beta=b, step0=0, n_steps=0)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         E.logdensity(spec.engine(device), torch.zeros(3, 30))
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _ext_arrays(rng, pkind, N, Cn, T, raw):
+    ext = rng.standard_normal((N, Cn, T, raw)).astype(np.float32)
+    if pkind == "Laplace":
+        ext = rng.random((N, Cn, T, raw)).astype(np.float32)
+    elif pkind == "UniformRadius":
+        ext[..., -1] = rng.random((N, Cn, T)).astype(np.float32)
+    return ext
+
+
+ALL_DIMS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 16, 17, 20, 29, 30, 31, 32, 33, 49, 50, 51, 63, 64, 65, 99, 100, 101, 104]
+
+
+@pytest.mark.parametrize("dim", ALL_DIMS)
+def test_every_register_width_vs_oracle(device, dim):
+    """Exact-width kernels (dims the reference's experiments use) and generic-width kernels (run-time dim with
+    predicated tails) for every boundary case of the width table, three-term RoughCarpet (modes +-4)."""
+    params = {"modes": np.float32([-4, 0, 4]), "weights": np.float32([0.2, 0.5, 0.3])}
+    spec = H.spec_from_params("RoughCarpetDistributionTorch", dim, params)
+    T, Cn, N = 3, 23, 24
+    beta = np.float32([1.0, 0.4, 0.1])
+    prop = H.proposal_spec("Normal", dim, beta, base_variance_scalar=2.38**2 / dim)
+    rng = np.random.default_rng(dim)
+    st = rng.normal(0, 3, (Cn, T, dim)).astype(np.float32)
+    lp = O.logdensity(spec.oracle(), st.reshape(-1, dim)).astype(np.float32).reshape(Cn, T)
+    ext = _ext_arrays(rng, "Normal", N, Cn, T, dim)
+    u = rng.random((N, Cn, T)).astype(np.float32)
+    us = rng.random((N // 4, Cn, T - 1)).astype(np.float32)
+    kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=3, swap_every=4, ext_prop=ext, ext_u=u,
+              ext_swap_u=us, want_flags=True)
+    want = O.run(spec.oracle(), prop.oracle(), trace_chains=Cn, trace_temps=T, **kw)
+    got = gpu_run(spec, prop, device, trace_temps=T, **kw)
+    first = H.first_mismatch(got["accept_flags"], want["accept_flags"])
+    upto = N if first is None else first
+    assert upto >= 6
+    assert np.array_equal(got["trace"][:upto], want["trace"][:upto])
+    if first is None:
+        assert np.array_equal(got["n_accept"], want["n_accept"]) and np.array_equal(got["swap_accept"], want["swap_accept"])
+    # Philox mode at the same width: decisions agree with the oracle's restated stream
+    kw2 = dict(state=st, logp=lp, beta=beta, step0=5, n_steps=N, burn_in=3, swap_every=4, seed=dim * 7919, chain_offset=3,
+               want_flags=True)
+    w2 = O.run(spec.oracle(), prop.oracle(), **kw2)
+    g2 = gpu_run(spec, prop, device, **kw2)
+    assert (g2["accept_flags"] == w2["accept_flags"]).mean() >= 0.99
+    own = O.logdensity(spec.oracle(), g2["state"].reshape(-1, dim), "f64").reshape(Cn, T)
+    logp_close(g2["logp"], own, extra_abs=3e-4)
+
+
+GENERIC_TARGETS = [
+    ("ThreeMixtureDistributionTorch", 12, {"means": np.float32(np.linspace(-3, 3, 36).reshape(3, 12)),
+                                            "mixing_weights": np.float32([0.3, 0.3, 0.4])}),
+    ("ThreeMixtureDistributionTorch", 12, {"means": np.float32(np.linspace(-3, 3, 36).reshape(3, 12)),
+                                            "mixing_weights": np.float32([0.3, 0.3, 0.4]),
+                                            "scaling_factors": np.float32(np.linspace(0.3, 1.7, 12))}),
+    ("RoughCarpetDistributionTorch", 13, {"modes": np.float32([-15, 0, 15]), "weights": np.float32([0.5, 0.3, 0.2]),
+                                           "scaling_factors": np.float32(np.linspace(0.5, 1.5, 13))}),
+    ("FullRosenbrockTorch", 9, {"a_coeff": np.float32(0.05), "b_coeff": np.float32(5), "mu": np.float32(np.linspace(0.8, 1.2, 8))}),
+    ("EvenRosenbrockTorch", 12, {"a_coeff": np.float32(0.05), "b_coeff": np.float32(5), "mu": np.float32(np.ones(6))}),
+    ("HybridRosenbrockTorch", 13, {"a_coeff": np.float32(0.05), "b_coeff": np.float32(5), "mu": np.float32(1), "n1": 4, "n2": 4}),
+    ("HybridRosenbrockTorch", 73, {"a_coeff": np.float32(0.05), "b_coeff": np.float32(5), "mu": np.float32(1), "n1": 7, "n2": 12}),
+    ("IIDGammaTorch", 7, {"shape": np.float32(2.0), "scale": np.float32(3.0)}),
+    ("IIDBetaTorch", 11, {"alpha": np.float32(2.0), "beta": np.float32(3.0)}),
+]
+
+
+@pytest.mark.parametrize("cls,dim,params", GENERIC_TARGETS, ids=[f"{c[0][:12]}-{c[1]}-{i}" for i, c in enumerate(GENERIC_TARGETS)])
+@pytest.mark.parametrize("pkind", ["Normal", "Laplace", "UniformRadius"])
+def test_generic_width_targets_vs_oracle(device, cls, dim, params, pkind):
+    """Every target functor through a run-time-dim (generic width) kernel, with every proposal."""
+    spec = H.spec_from_params(cls, dim, params)
+    T, Cn, N = 4, 17, 30
+    beta = np.float32([1.0, 0.5, 0.2, 0.05])
+    scale = 0.02 if "Rosenbrock" in cls or "Beta" in cls else 0.5
+    pkw = {"Normal": dict(base_variance_scalar=scale), "Laplace": dict(base_variance_vector=np.full(dim, scale)),
+           "UniformRadius": dict(base_radius=float(np.sqrt(scale * (dim + 2))))}[pkind]
+    prop = H.proposal_spec(pkind, dim, beta, **pkw)
+    rng = np.random.default_rng(zlib.crc32(f"{cls}{dim}{pkind}".encode()))
+    st, lp = start_state(spec, Cn, T, rng)
+    raw = O.ext_raw_per_step(prop.kind, dim)
+    kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=4, swap_every=5,
+              ext_prop=_ext_arrays(rng, pkind, N, Cn, T, raw), ext_u=rng.random((N, Cn, T)).astype(np.float32),
+              ext_swap_u=rng.random((N // 5, Cn, T - 1)).astype(np.float32), want_flags=True)
+    want = O.run(spec.oracle(), prop.oracle(), trace_chains=Cn, trace_temps=T, **kw)
+    got = gpu_run(spec, prop, device, trace_temps=T, **kw)
+    first = H.first_mismatch(got["accept_flags"], want["accept_flags"])
+    upto = N if first is None else first
+    assert upto >= 8
+    if pkind == "Normal":
+        assert np.array_equal(got["trace"][:upto], want["trace"][:upto])
+    else:
+        np.testing.assert_allclose(got["trace"][:upto], want["trace"][:upto], rtol=1e-4, atol=1e-5)
+    own = O.logdensity(spec.oracle(), got["trace"].reshape(-1, dim), "f64").reshape(got["trace_logp"].shape)
+    logp_close(got["trace_logp"], own, extra_abs=3e-4)
+    if first is None:
+        assert np.array_equal(got["n_accept"], want["n_accept"]) and np.array_equal(got["swap_accept"], want["swap_accept"])
+
+
+@pytest.mark.parametrize("T,Cn", [(64, 3), (33, 2), (63, 5), (21, 4), (2, 100), (1, 1), (32, 1)])
+def test_ladder_shapes_vs_oracle(device, T, Cn):
+    """Ladders that fill a wavefront exactly, leave idle lanes (T not dividing 64), or span several waves."""
+    spec = H.target_spec("rc15_d30")
+    beta = (0.02 ** (np.arange(T) / max(1, T - 1))).astype(np.float32)
+    prop = H.proposal_spec("Normal", 30, beta, base_variance_scalar=2.38**2 / 30)
+    rng = np.random.default_rng(T * 1000 + Cn)
+    st, lp = start_state(spec, Cn, T, rng)
+    N = 40
+    for order in ("sequential", "even_odd"):
+        kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=2, swap_every=3,
+                  ext_prop=rng.standard_normal((N, Cn, T, 30)).astype(np.float32),
+                  ext_u=rng.random((N, Cn, T)).astype(np.float32),
+                  ext_swap_u=rng.random((N // 3, Cn, T - 1)).astype(np.float32) if T > 1 else None,
+                  swap_order=E.SWAP_ORDERS[order], want_flags=True)
+        want = O.run(spec.oracle(), prop.oracle(), trace_chains=Cn, trace_temps=T, **kw)
+        got = gpu_run(spec, prop, device, trace_temps=T, **kw)
+        first = H.first_mismatch(got["accept_flags"], want["accept_flags"])
+        upto = N if first is None else first
+        assert upto >= 8
+        assert np.array_equal(got["trace"][:upto], want["trace"][:upto])
+        if first is None:
+            for k in ("n_accept", "swap_accept", "last_swap_ordinal"):
+                assert np.array_equal(got[k], want[k]), (k, order)
+
+
+def test_zero_chains_and_support_edges(device):
+    spec = H.target_spec("beta_d5")
+    prop = H.proposal_spec("Normal", 5, [1.0], base_variance_scalar=0.5, single=True)
+    # empty batch: nothing is launched, nothing is touched
+    E.run(spec.engine(device), prop.engine(device), state=torch.zeros(0, 1, 5, device=device),
+          logp=torch.zeros(0, 1, device=device), beta=torch.ones(1, device=device), step0=0, n_steps=10)
+    # a chain started OUTSIDE the support (log p = -inf) accepts its first in-support proposal and never leaves
+    st = np.full((64, 1, 5), 1.05, np.float32)
+    lp = np.full((64, 1), -np.inf, np.float32)
+    got = gpu_run(spec, prop, device, state=st, logp=lp, beta=[1.0], step0=0, n_steps=400, seed=3, want_flags=True)
+    want = O.run(spec.oracle(), prop.oracle(), state=st, logp=lp, beta=[1.0], step0=0, n_steps=400, seed=3, want_flags=True)
+    inside = np.all((got["state"] > 0) & (got["state"] < 1), axis=2)
+    assert np.array_equal(np.isfinite(got["logp"]), inside)
+    assert inside.mean() > 0.5
+    assert (got["accept_flags"] == want["accept_flags"]).mean() > 0.995
