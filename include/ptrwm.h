@@ -150,12 +150,12 @@ typedef struct ptrwm_run_args {
   const float *ext_u;      /* [n_steps, n_chains, n_temps] accept uniforms */
   const float *ext_swap_u; /* [n_swap_events_in_call, n_chains, n_temps-1] */
   /* optional per-step outputs */
-  float *trace;        /* [trace_rows, trace_chains, trace_temps, dim] state after each step of this call */
+  float *trace;        /* [trace_rows, trace_chains, trace_temps, dim] state after each traced step of this call */
   float *trace_logp;   /* [trace_rows, trace_chains, trace_temps] */
   int64_t trace_chains; /* first trace_chains local chains are traced */
   int32_t trace_temps;  /* first trace_temps temperatures are traced (1 = cold chain only) */
-  int32_t reserved1;
-  int64_t trace_row0;   /* row written by the first step of this call */
+  int32_t trace_every;  /* thinning: a step is traced when step_counter % trace_every == 0 (0 or 1 = every step) */
+  int64_t trace_row0;   /* row written by the first traced step of this call */
   uint8_t *accept_flags; /* [n_steps, n_chains, n_temps] MH accept decision of every step, or NULL */
 } ptrwm_run_args;
 

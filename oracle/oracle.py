@@ -41,7 +41,7 @@ class RunArgs(C.Structure):
         ("swap_mode", C.c_int32), ("swap_order", C.c_int32), ("reserved0", C.c_int32), ("seed", C.c_uint64),
         ("ext_prop", C.c_void_p), ("ext_u", C.c_void_p), ("ext_swap_u", C.c_void_p), ("trace", C.c_void_p),
         ("trace_logp", C.c_void_p), ("trace_chains", C.c_int64), ("trace_temps", C.c_int32),
-        ("reserved1", C.c_int32), ("trace_row0", C.c_int64), ("accept_flags", C.c_void_p),
+        ("trace_every", C.c_int32), ("trace_row0", C.c_int64), ("accept_flags", C.c_void_p),
     ]
 
 

@@ -79,8 +79,12 @@ class EngineRun:
         self.last_ord = torch.zeros(shape, device=device, dtype=torch.int64)
 
     # ---- stepping ---------------------------------------------------------------------------
+    def traced_rows(self, n_steps: int, every: int) -> int:
+        """Rows a trace with thinning period `every` receives from the next n_steps steps."""
+        return (self.steps_done + n_steps) // every - self.steps_done // every
+
     def advance(self, n_steps: int, trace: Optional[torch.Tensor] = None, trace_logp: Optional[torch.Tensor] = None,
-                trace_row0: int = 0) -> None:
+                trace_row0: int = 0, trace_every: int = 1) -> None:
         """Enqueue n_steps fused steps (no host synchronisation)."""
         if n_steps <= 0:
             return
@@ -89,7 +93,7 @@ class EngineRun:
             n_steps=n_steps, burn_in=self.burn_in, swap_every=self.swap_every, swap_mode=self.swap_mode,
             swap_order=self.swap_order, seed=self.seed, chain_offset=self.chain_offset, n_accept=self.n_accept,
             sq_jump=self.sq_jump, swap_accept=self.swap_accept, last_swap_ordinal=self.last_ord, trace=trace,
-            trace_logp=trace_logp, trace_row0=trace_row0,
+            trace_logp=trace_logp, trace_row0=trace_row0, trace_every=trace_every,
         )
         self.steps_done += n_steps
 

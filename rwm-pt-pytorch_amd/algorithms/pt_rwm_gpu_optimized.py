@@ -54,7 +54,7 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
                  pre_allocate_steps: int = None, dtype: torch.dtype = torch.float32, *,
                  num_replicas: int = 1, proposal_distribution: Optional[ProposalDistribution] = None,
                  swap_mode: str = "exchange", swap_order: str = "sequential", seed: Optional[int] = None,
-                 chain_offset: int = 0, trace: str = "all"):
+                 chain_offset: int = 0, trace: str = "all", thin: int = 1):
         super().__init__(dim, var, target_dist, symmetric)
         self.device = resolve_device(device)
         if dtype != torch.float32:
@@ -67,6 +67,9 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
         if trace not in ("all", "cold", "none"):
             raise ValueError("trace must be 'all', 'cold' or 'none'")
         self._trace_mode = trace
+        if thin < 1:
+            raise ValueError("thin must be >= 1")
+        self.thin = int(thin)  # store every thin-th state (1 = every state, the reference behaviour)
 
         self.use_torch_target = isinstance(self.target_dist, TorchTargetDistribution)
         if not self.use_torch_target:
@@ -108,7 +111,7 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
         self._seed, self._chain_offset = seed, chain_offset
 
         self.pre_allocate_steps = pre_allocate_steps
-        self._alloc_trace(self.burn_in + pre_allocate_steps + 1 if pre_allocate_steps else 0)
+        self._alloc_trace((self.burn_in + pre_allocate_steps) // self.thin + 1 if pre_allocate_steps else 0)
         self.step_counter = 0
         self._run: Optional[EngineRun] = None
         self._chain_cache = None
@@ -210,10 +213,11 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
     def _advance(self, n_steps: int):
         self._ensure_started()
         if self._trace_mode != "none":
-            if self._trace is None or self._rows_used + n_steps > self._trace_rows:
+            rows = self._run.traced_rows(n_steps, self.thin)
+            if self._trace is None or self._rows_used + rows > self._trace_rows:
                 # no (or too small a) pre-allocation: grow the device-side chain storage
                 old, old_lp, used = self._trace, self._trace_logp, self._rows_used
-                self._alloc_trace(max(used, 1) + n_steps)
+                self._alloc_trace(max(used, 1) + rows)
                 if old is not None and used:
                     self._trace[:used] = old[:used]
                     self._trace_logp[:used] = old_lp[:used]
@@ -225,8 +229,9 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
                     self._trace_logp[0, 0] = self._run.logp[0, :nt]
                     self._rows_used = 1
                     self.chain_indices[:] = 1
-            self._run.advance(n_steps, trace=self._trace, trace_logp=self._trace_logp, trace_row0=self._rows_used)
-            self._rows_used += n_steps
+            self._run.advance(n_steps, trace=self._trace, trace_logp=self._trace_logp, trace_row0=self._rows_used,
+                              trace_every=self.thin)
+            self._rows_used += rows
             self.chain_indices[:] = self._rows_used
         else:
             self._run.advance(n_steps)
@@ -264,7 +269,7 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
               f"swap accept {self.swap_acceptance_rate:.3f})")
         if self._trace_mode == "none":
             return torch.empty(0, self.dim, device=self.device)
-        return self.get_cold_chain_gpu()[1 + self.burn_in:]
+        return self.get_cold_chain_gpu()[1 + self.burn_in // self.thin:]
 
     # ---- chains ----------------------------------------------------------------------------------------
     def get_all_chains_gpu(self):

@@ -56,7 +56,7 @@ class RandomWalkMH_GPU_Optimized(MHAlgorithm):
     def __init__(self, dim: int, var: float = None, target_dist=None, symmetric: bool = True, beta: float = 1.0,
                  burn_in: int = 0, device: str = None, pre_allocate_steps: int = None, use_efficient_rng: bool = True,
                  compile_mode: str = None, proposal_distribution: ProposalDistribution = None, *,
-                 num_chains: int = 1, seed: Optional[int] = None, chain_offset: int = 0):
+                 num_chains: int = 1, seed: Optional[int] = None, chain_offset: int = 0, thin: int = 1):
         if proposal_distribution is None and var is None:
             raise ValueError("Either var (backward compatibility) or proposal_distribution must be provided")
         super().__init__(dim, 1.0 if proposal_distribution is not None else var, target_dist, symmetric)
@@ -89,9 +89,12 @@ class RandomWalkMH_GPU_Optimized(MHAlgorithm):
         self.num_chains = int(num_chains)
         self._seed, self._chain_offset = seed, chain_offset
         self.total_steps = 0
+        if thin < 1:
+            raise ValueError("thin must be >= 1")
+        self.thin = int(thin)  # store every thin-th state of chain 0 (1 = every state, the reference behaviour)
         self.pre_allocate_steps = pre_allocate_steps
         if pre_allocate_steps:
-            rows = self.burn_in + pre_allocate_steps + 1  # + initial state
+            rows = (self.burn_in + pre_allocate_steps) // self.thin + 1  # + initial state
             self._trace = torch.zeros((rows, 1, 1, dim), device=self.device, dtype=self.dtype)
             self._trace_logp = torch.zeros((rows, 1, 1), device=self.device, dtype=torch.float32)
             self.pre_allocated_chain = self._trace.view(rows, dim)
@@ -157,19 +160,21 @@ class RandomWalkMH_GPU_Optimized(MHAlgorithm):
     def _advance(self, n_steps: int):
         """n_steps fused MH steps; chain 0's states go to the pre-allocated chain or the Python list."""
         self._ensure_started()
-        if self.pre_allocated_chain is not None and self.chain_index + n_steps > self.pre_allocated_chain.shape[0]:
+        rows = self._run.traced_rows(n_steps, self.thin)
+        if self.pre_allocated_chain is not None and self.chain_index + rows > self.pre_allocated_chain.shape[0]:
             warnings.warn("Pre-allocated chain full, switching to dynamic allocation")
             kept = self.pre_allocated_chain[1:self.chain_index].cpu().numpy()
             self.chain.extend(list(kept))
             self.pre_allocated_chain = self.pre_allocated_log_densities = None
             self._trace = self._trace_logp = None
         if self.pre_allocated_chain is not None:
-            self._run.advance(n_steps, trace=self._trace, trace_logp=self._trace_logp, trace_row0=self.chain_index)
-            self.chain_index += n_steps
+            self._run.advance(n_steps, trace=self._trace, trace_logp=self._trace_logp, trace_row0=self.chain_index,
+                              trace_every=self.thin)
+            self.chain_index += rows
         else:
-            tr = torch.empty((n_steps, 1, 1, self.dim), device=self.device, dtype=self.dtype)
-            self._run.advance(n_steps, trace=tr)
-            self.chain.extend(list(tr.view(n_steps, self.dim).cpu().numpy()))
+            tr = torch.empty((max(rows, 1), 1, 1, self.dim), device=self.device, dtype=self.dtype)
+            self._run.advance(n_steps, trace=tr, trace_every=self.thin)
+            self.chain.extend(list(tr[:rows].view(rows, self.dim).cpu().numpy()))
         self.total_steps += n_steps
 
     def step(self):
@@ -187,7 +192,7 @@ class RandomWalkMH_GPU_Optimized(MHAlgorithm):
         print(f"Generated {num_samples} samples (+ {self.burn_in} burn-in) x {self.num_chains} chain(s) with the fused "
               f"HIP kernel in {dt:.3f}s ({total_steps * self.num_chains / dt:.3e} chain-steps/s, "
               f"accept {self.acceptance_rate:.3f})")
-        return self.get_chain_gpu()[1 + self.burn_in:]
+        return self.get_chain_gpu()[1 + self.burn_in // self.thin:]
 
     # ---- read-outs ---------------------------------------------------------------------------------
     def get_chain_gpu(self):
@@ -205,9 +210,8 @@ class RandomWalkMH_GPU_Optimized(MHAlgorithm):
         """Mean squared jump over the post-burn-in steps (reference :513-534), accumulated online by the
         kernel in fp64 instead of being recomputed from the stored chain; averaged over all chains."""
         run = self._run
-        stored = self.chain_index if self.pre_allocated_chain is not None else len(self.chain)
-        if run is None or stored <= self.burn_in + 1:
-            raise ValueError(f"Insufficient post-burn-in samples: have {stored}, burn_in={self.burn_in}. "
+        if run is None or run.post_burn_steps < 1:
+            raise ValueError(f"Insufficient post-burn-in samples: total_steps={self.total_steps}, burn_in={self.burn_in}. "
                              f"Need at least {self.burn_in + 2} total samples.")
         return float(run.sq_jump.sum().item()) / (run.post_burn_steps * run.n_replicas)
 

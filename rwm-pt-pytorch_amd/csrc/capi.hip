@@ -173,7 +173,8 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   const bool ext = args->ext_prop != nullptr;
   if (ext && args->ext_u == nullptr) return PTRWM_E_NULL;
   if (args->trace != nullptr && (args->trace_chains < 1 || args->trace_temps < 1 || args->trace_row0 < 0 ||
-                                 args->trace_temps > args->n_temps || args->trace_chains > args->n_chains))
+                                 args->trace_temps > args->n_temps || args->trace_chains > args->n_chains ||
+                                 args->trace_every < 0))
     return PTRWM_E_ARG;
 
   const int dpi = width_index_for_dim(target->dim);
@@ -228,6 +229,8 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   // One launch covers at most kMaxStepsPerLaunch steps (32-bit in-kernel counters, bounded kernel
   // run time); longer requests become back-to-back launches on the same stream.
   const long long kMaxStepsPerLaunch = 1 << 20;
+  const long long te = args->trace_every > 1 ? args->trace_every : 1;
+  k.full.trace_every = (int)te;
   const long long reps = args->n_chains * args->n_temps;
   const long long raw = k.full.n_raw_ext;
   long long done = 0;
@@ -247,7 +250,9 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
                             ? args->ext_swap_u + (ev0 - events_upto(args->step0)) * args->n_chains * (args->n_temps - 1)
                             : nullptr;
     k.full.accept_flags = args->accept_flags != nullptr ? args->accept_flags + done * reps : nullptr;
-    k.full.trace_row0 = args->trace_row0 + done;
+    // traced steps are those whose step_counter is a multiple of trace_every: rows before this launch
+    k.full.trace_row0 = args->trace_row0 + (step0 / te - args->step0 / te);
+    k.full.steps_to_trace = (int)(te - step0 % te);
     const hipError_t err = fn(k, (unsigned)n_blocks, full, (hipStream_t)stream);
     if (err != hipSuccess) return PTRWM_E_LAUNCH;
     done += n;

@@ -32,6 +32,8 @@ struct FullArgs {
   unsigned char *__restrict__ accept_flags;
   long long trace_chains, trace_row0;
   int trace_temps, n_raw_ext;
+  int trace_every;     // thinning period (>= 1)
+  int steps_to_trace;  // steps until the first traced step of this launch (1 = the first step)
 };
 
 struct KArgs {
@@ -133,6 +135,8 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
   const bool trace_on =
       FULL && live && a.full.trace != nullptr && (chain < a.full.trace_chains) && (t < a.full.trace_temps);
   int to_swap = a.steps_to_swap;
+  int to_trace = FULL ? a.full.steps_to_trace : 0;
+  int trace_rows = 0;    // rows of the trace written by this launch
   int swap_in_call = 0;  // swap events already done in this launch
   const int ev_par0 = (int)(a.first_swap_event & 1);
   unsigned long long s = (unsigned long long)a.step0;  // 0-based global step index
@@ -286,14 +290,21 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       sq += (double)j2;
     }
     if constexpr (FULL) {
-      if (trace_on) {
-        const long long row = ((a.full.trace_row0 + i) * a.full.trace_chains + chain) * a.full.trace_temps + t;
+      bool trace_now = false;
+      if (a.full.trace != nullptr) {  // wave-uniform thinning countdown
+        --to_trace;
+        trace_now = (to_trace == 0);
+        if (trace_now) to_trace = a.full.trace_every;
+      }
+      if (trace_now && trace_on) {
+        const long long row = ((a.full.trace_row0 + trace_rows) * a.full.trace_chains + chain) * a.full.trace_temps + t;
         float *__restrict__ tr = a.full.trace + row * D;
 #pragma unroll
         for (int d = 0; d < DP; ++d)
           if (d < D) tr[d] = x[d];
         if (a.full.trace_logp != nullptr) a.full.trace_logp[row] = lp;
       }
+      trace_rows += trace_now ? 1 : 0;
     }
   }
 

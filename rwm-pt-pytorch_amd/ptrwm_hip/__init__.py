@@ -101,7 +101,7 @@ class RunArgs(C.Structure):
         ("trace_logp", C.c_void_p),
         ("trace_chains", C.c_int64),
         ("trace_temps", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("trace_every", C.c_int32),
         ("trace_row0", C.c_int64),
         ("accept_flags", C.c_void_p),
     ]
@@ -298,6 +298,7 @@ def run(
     trace: Optional[torch.Tensor] = None,  # [rows, trace_chains, trace_temps, D]
     trace_logp: Optional[torch.Tensor] = None,
     trace_row0: int = 0,
+    trace_every: int = 1,
     accept_flags: Optional[torch.Tensor] = None,  # [n_steps, C, T] uint8
 ) -> None:
     """Enqueue ``n_steps`` fused MH(+swap) steps for every (chain, temperature) replica."""
@@ -343,8 +344,11 @@ def run(
     a.trace = _opt(trace, "trace", torch.float32)
     a.trace_logp = _opt(trace_logp, "trace_logp", torch.float32)
     if trace is not None:
-        if trace.dim() != 4 or trace.shape[3] != D or trace.shape[0] < trace_row0 + n_steps:
-            raise ValueError("trace must be [rows >= trace_row0 + n_steps, trace_chains, trace_temps, dim]")
+        te = max(1, int(trace_every))
+        rows = (step0 + n_steps) // te - step0 // te  # steps of this call whose step_counter is a multiple of te
+        if trace.dim() != 4 or trace.shape[3] != D or trace.shape[0] < trace_row0 + rows:
+            raise ValueError("trace must be [rows >= trace_row0 + traced steps, trace_chains, trace_temps, dim]")
+        a.trace_every = te
         a.trace_chains = trace.shape[1]
         a.trace_temps = trace.shape[2]
     a.trace_row0 = trace_row0

@@ -294,3 +294,39 @@ def test_fused_step_helper_matches_kernel_rule(device):
                                                torch.tensor(0.9, device=device), torch.tensor(1.0, device=device),
                                                torch.tensor(-float("inf"), device=device))
     assert not bool(acc) and torch.equal(new, x)
+
+
+def test_thinned_chain_storage(device):
+    """thin=k stores every k-th state (steps whose counter is a multiple of k); statistics are unaffected and the
+    stored rows are exactly the corresponding rows of the unthinned run, also across several calls."""
+    dim = 10
+    target = ThreeMixtureDistributionTorch(dim, device=device)
+
+    def rwm(thin, pre):
+        return RandomWalkMH_GPU_Optimized(dim, 0.3, target, burn_in=30, device=device, pre_allocate_steps=pre,
+                                          seed=11, thin=thin)
+
+    full, thin = rwm(1, 1000), rwm(7, 1000)
+    s_full, s_thin = full.generate_samples(1000), thin.generate_samples(1000)
+    assert s_full.shape == (1000, dim) and s_thin.shape == ((1030 // 7) - 30 // 7, dim)
+    chain = full.get_chain_gpu()
+    assert torch.equal(thin.get_chain_gpu()[0], chain[0])
+    assert torch.equal(thin.get_chain_gpu()[1:], chain[7::7])
+    assert torch.equal(s_thin, chain[7::7][30 // 7:])
+    assert thin.acceptance_rate == full.acceptance_rate
+    assert thin.expected_squared_jump_distance_gpu() == full.expected_squared_jump_distance_gpu()
+    # several calls, no pre-allocation (dynamic storage)
+    dyn = rwm(7, None)
+    for n in (3, 4, 10, 500, 513):
+        dyn._advance(n)
+    assert torch.equal(dyn.get_chain_gpu(), thin.get_chain_gpu())
+
+    ladder = geometric_beta_ladder(5)
+    kw = dict(beta_ladder=ladder, swap_every=4, burn_in=10, device=device, seed=5)
+    a = ParallelTemperingRWM_GPU_Optimized(dim, 0.3, target, pre_allocate_steps=200, **kw)
+    b = ParallelTemperingRWM_GPU_Optimized(dim, 0.3, target, thin=5, **kw)
+    ca, cb = a.generate_samples(200), b.generate_samples(200)
+    assert cb.shape == (210 // 5 - 2, dim)
+    for t in range(5):
+        assert torch.equal(b.get_all_chains_gpu()[t][1:], a.get_all_chains_gpu()[t][5::5])
+    assert a.swap_acceptance_rate == b.swap_acceptance_rate
