@@ -69,7 +69,17 @@ enum {
   PTRWM_TARGET_IID_GAMMA = 5,
   /* iid_product_torch.py:188-229 IIDBetaTorch: p[0]=alpha, p[1]=beta, p[2]=log_norm_const (dim * 1d) */
   PTRWM_TARGET_IID_BETA = 6,
-  PTRWM_TARGET_COUNT = 7
+  /* Gaussians with diagonal structure:
+   *   ip[0] = 0: multivariate_normal_torch.py:62-92 MultivariateNormalTorch with a DIAGONAL covariance:
+   *              -0.5 sum_d vec1[d] (x_d - vec0[d])^2 + p[0];  vec0 = mean, vec1 = diag(cov_inv), p[0] = log_norm_const
+   *   ip[0] = 1: multivariate_normal_torch.py:199-224 ScaledMultivariateNormalTorch:
+   *              p[0] - 0.5 sum_d (vec0[d] x_d)^2;  vec0 = scaling_factors, p[0] = log_norm_const */
+  PTRWM_TARGET_DIAG_GAUSSIAN = 7,
+  /* hypercube_torch.py:49-78 HypercubeTorch: p[0] = left, p[1] = right, p[2] = log uniform density; -inf outside */
+  PTRWM_TARGET_HYPERCUBE = 8,
+  /* funnel_torch.py:39-76 NealFunnelTorch: p[0] = mu_v, p[1] = sigma_v^2, p[2] = mu_z; x[0] = v, x[1..] = z */
+  PTRWM_TARGET_NEAL_FUNNEL = 9,
+  PTRWM_TARGET_COUNT = 10
 };
 
 typedef struct ptrwm_target_desc {

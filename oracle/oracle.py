@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 TARGET_ROUGH_CARPET, TARGET_THREE_MIXTURE, TARGET_FULL_ROSENBROCK, TARGET_EVEN_ROSENBROCK = 0, 1, 2, 3
 TARGET_HYBRID_ROSENBROCK, TARGET_IID_GAMMA, TARGET_IID_BETA = 4, 5, 6
+TARGET_DIAG_GAUSSIAN, TARGET_HYPERCUBE, TARGET_NEAL_FUNNEL = 7, 8, 9
 PROPOSAL_NORMAL, PROPOSAL_LAPLACE, PROPOSAL_UNIFORM_RADIUS = 0, 1, 2
 SWAP_EXCHANGE, SWAP_REFERENCE_COPY = 0, 1
 ORDER_SEQUENTIAL, ORDER_EVEN_ODD = 0, 1

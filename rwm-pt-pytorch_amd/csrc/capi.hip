@@ -14,6 +14,9 @@ static const TargetVariants *target_variants(int kind, bool two_term = false) {
     case PTRWM_TARGET_HYBRID_ROSENBROCK: return &hybrid_rosenbrock_variants();
     case PTRWM_TARGET_IID_GAMMA: return &iid_gamma_variants();
     case PTRWM_TARGET_IID_BETA: return &iid_beta_variants();
+    case PTRWM_TARGET_DIAG_GAUSSIAN: return &diag_gaussian_variants();
+    case PTRWM_TARGET_HYPERCUBE: return &hypercube_variants();
+    case PTRWM_TARGET_NEAL_FUNNEL: return &neal_funnel_variants();
     default: return nullptr;
   }
 }
@@ -33,6 +36,9 @@ static int check_target(const ptrwm_target_desc *t) {
     case PTRWM_TARGET_EVEN_ROSENBROCK:
       if (t->dim < 2 || (t->dim & 1)) return PTRWM_E_DIM;
       if (t->vec0 == nullptr) return PTRWM_E_NULL;
+      break;
+    case PTRWM_TARGET_DIAG_GAUSSIAN:
+      if (t->vec0 == nullptr || (t->ip[0] == 0 && t->vec1 == nullptr)) return PTRWM_E_NULL;
       break;
     case PTRWM_TARGET_HYBRID_ROSENBROCK:
       if (t->ip[0] < 2 || t->ip[1] < 1) return PTRWM_E_ARG;

@@ -243,4 +243,76 @@ struct IIDBeta {
   }
 };
 
+// MultivariateNormalTorch.log_density with a diagonal covariance (multivariate_normal_torch.py:62-92; the dense
+// [B,D]x[D,D] product is out of scope) and ScaledMultivariateNormalTorch.log_density (:199-224).
+template <int DP>
+struct DiagGaussian {
+  static constexpr int kKind = PTRWM_TARGET_DIAG_GAUSSIAN;
+  template <bool SCALED_FORM>
+  __device__ __forceinline__ static float quad(const float (&y)[DP], int D, const TParams &tp) {
+    float q = 0.0f;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      if (d < D) {
+        if constexpr (SCALED_FORM) {
+          const float sx = tp.vec0[d] * y[d];
+          q = fmaf(sx, sx, q);
+        } else {
+          const float c = y[d] - tp.vec0[d];
+          q = fmaf(c * tp.vec1[d], c, q);
+        }
+      }
+      if ((d & 7) == 7) sched_fence();
+    }
+    return q;
+  }
+  template <bool STRICT = false>
+  __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+    const float q = tp.ip[0] != 0 ? quad<true>(y, D, tp) : quad<false>(y, D, tp);
+    return fmaf(-0.5f, q, tp.p[0]);
+  }
+};
+
+// HypercubeTorch.log_density, hypercube_torch.py:49-78: log(1/volume) inside [left, right]^D (closed), -inf outside.
+template <int DP>
+struct Hypercube {
+  static constexpr int kKind = PTRWM_TARGET_HYPERCUBE;
+  template <bool STRICT = false>
+  __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+    const float lo = tp.p[0], hi = tp.p[1];
+    bool inside = true;
+#pragma unroll
+    for (int d = 0; d < DP; ++d)
+      if (d < D) inside = inside && (y[d] >= lo) && (y[d] <= hi);
+    return inside ? tp.p[2] : kNegInf;
+  }
+};
+
+// NealFunnelTorch.log_density, funnel_torch.py:39-76:
+//   -0.5 log 2pi - 0.5 log s2 - 0.5 (v - mu_v)^2 / s2 - 0.5 (D-1) log 2pi - 0.5 (D-1) v - 0.5 exp(-v) sum_k (z_k - mu_z)^2
+template <int DP>
+struct NealFunnel {
+  static constexpr int kKind = PTRWM_TARGET_NEAL_FUNNEL;
+  template <bool STRICT = false>
+  __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+    const float mu_v = tp.p[0], s2 = tp.p[1], mu_z = tp.p[2];
+    const float log_2pi = 1.8378770664093453f;
+    const float v = y[0];
+    const float dv = v - mu_v;
+    const float prior = -0.5f * log_2pi - 0.5f * (hw_log2(s2) * kLn2) - 0.5f * (dv * dv) / s2;
+    float ss = 0.0f;
+#pragma unroll
+    for (int d = 1; d < DP; ++d) {
+      if (d < D) {
+        const float c = y[d] - mu_z;
+        ss = fmaf(c, c, ss);
+      }
+      if ((d & 7) == 7) sched_fence();
+    }
+    const float dm1 = (float)(D - 1);
+    const float lik = -0.5f * dm1 * log_2pi - 0.5f * dm1 * v - 0.5f * hw_exp(-v) * ss;
+    return D > 1 ? prior + lik : prior;
+  }
+};
+
 }  // namespace ptrwm

@@ -88,5 +88,8 @@ const TargetVariants &even_rosenbrock_variants();
 const TargetVariants &hybrid_rosenbrock_variants();
 const TargetVariants &iid_gamma_variants();
 const TargetVariants &iid_beta_variants();
+const TargetVariants &diag_gaussian_variants();
+const TargetVariants &hypercube_variants();
+const TargetVariants &neal_funnel_variants();
 
 }  // namespace ptrwm

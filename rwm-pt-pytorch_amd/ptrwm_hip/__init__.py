@@ -31,6 +31,9 @@ TARGET_EVEN_ROSENBROCK = 3
 TARGET_HYBRID_ROSENBROCK = 4
 TARGET_IID_GAMMA = 5
 TARGET_IID_BETA = 6
+TARGET_DIAG_GAUSSIAN = 7
+TARGET_HYPERCUBE = 8
+TARGET_NEAL_FUNNEL = 9
 # proposal kinds
 PROPOSAL_NORMAL = 0
 PROPOSAL_LAPLACE = 1

@@ -1,7 +1,11 @@
-"""Target densities the fused HIP kernel evaluates (the in-scope subset)."""
+"""Target densities the fused HIP kernel evaluates: the in-scope subset plus the cheap
+"next" targets of section 8f-3 (diagonal MVN, ScaledMVN, Hypercube, NealFunnel)."""
 from .multimodal_torch import RoughCarpetDistributionTorch, ThreeMixtureDistributionTorch
 from .rosenbrock_torch import EvenRosenbrockTorch, FullRosenbrockTorch, HybridRosenbrockTorch
 from .iid_product_torch import IIDBetaTorch, IIDGammaTorch
+from .multivariate_normal_torch import MultivariateNormalTorch, ScaledMultivariateNormalTorch
+from .hypercube_torch import HypercubeTorch
+from .funnel_torch import NealFunnelTorch
 
 __all__ = [
     "RoughCarpetDistributionTorch",
@@ -11,4 +15,8 @@ __all__ = [
     "HybridRosenbrockTorch",
     "IIDGammaTorch",
     "IIDBetaTorch",
+    "MultivariateNormalTorch",
+    "ScaledMultivariateNormalTorch",
+    "HypercubeTorch",
+    "NealFunnelTorch",
 ]

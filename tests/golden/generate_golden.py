@@ -75,6 +75,15 @@ def make_targets():
     T["gamma_d5"] = ref_tgt.IIDGammaTorch(5, shape=3.5, scale=0.7, device="cpu")
     T["beta_d50"] = ref_tgt.IIDBetaTorch(50, device="cpu")
     T["beta_d5"] = ref_tgt.IIDBetaTorch(5, alpha=1.5, beta=4.0, device="cpu")
+    # section 8f-3 targets
+    T["mvn_d50"] = ref_tgt.MultivariateNormalTorch(50, device="cpu")
+    T["mvnd_d8"] = ref_tgt.MultivariateNormalTorch(8, mean=list(np.linspace(-1, 1, 8)),
+                                                   cov=np.diag(np.linspace(0.3, 2.5, 8)).tolist(), device="cpu")
+    T["smvn_d20"] = ref_tgt.ScaledMultivariateNormalTorch(20, device="cpu", seed=77)
+    T["cube_d5"] = ref_tgt.HypercubeTorch(5, device="cpu")
+    T["cube2_d3"] = ref_tgt.HypercubeTorch(3, left_boundary=-2.0, right_boundary=1.5, device="cpu")
+    T["funnel_d10"] = ref_tgt.NealFunnelTorch(10, device="cpu")
+    T["funnel_d1"] = ref_tgt.NealFunnelTorch(1, mu_v=0.5, sigma_v_sq=4.0, device="cpu")
     return T
 
 
@@ -82,7 +91,8 @@ def target_params(key, t):
     """The constructor-level parameters a test needs to rebuild the same target."""
     p = {"class": type(t).__name__, "dim": int(t.dim), "name": t.get_name()}
     for attr in ("modes", "weights", "means", "mixing_weights", "scaling_factors", "mu", "a_coeff", "b_coeff",
-                 "shape", "scale", "alpha", "beta"):
+                 "shape", "scale", "alpha", "beta", "mean", "cov", "log_norm_const", "left_boundary", "right_boundary",
+                 "log_uniform_density", "mu_v", "sigma_v_sq", "mu_z"):
         if hasattr(t, attr):
             p[attr] = np.asarray(getattr(t, attr).detach().cpu().numpy(), dtype=np.float32)
     for attr in ("n1", "n2"):
@@ -94,7 +104,14 @@ def target_params(key, t):
 def points_for(key, t, rng):
     D = t.dim
     anchors = np.stack([np.linspace(-2, 2, D), np.linspace(-16, 16, D), np.zeros(D), np.full(D, 0.5)])
-    if key.startswith("beta"):
+    if key.startswith("cube"):
+        lo, hi = float(t.left_boundary), float(t.right_boundary)
+        rnd = rng.uniform(lo - 0.2 * (hi - lo), hi + 0.2 * (hi - lo), size=(60, D))
+        rnd[:20] = rng.uniform(lo, hi, size=(20, D))
+        rnd[0, 0], rnd[1, 0] = lo, hi  # the closed boundary belongs to the support
+    elif key.startswith(("mvn", "smvn", "funnel")):
+        rnd = rng.normal(0.0, 2.0, size=(60, D))
+    elif key.startswith("beta"):
         rnd = rng.uniform(0.01, 0.99, size=(60, D))
         rnd[:6, 0] = [-0.1, 0.0, 1.0, 1.2, 0.5, 1e-6]  # outside / on the boundary of the support
     elif key.startswith("gamma"):
@@ -203,6 +220,10 @@ def gen_rwm(T):
         ("rwm_beta_uniform", "beta_d5", "UniformRadius", 0.35, 1.0, 1000, 100, 49),
         ("rwm_rc15s_normal", "rc15s_d10", "Normal", 2.38**2 / 10, 1.0, 1000, 100, 50),
         ("rwm_tms_normal", "tms_d10", "Normal", 2.38**2 / 10, 1.0, 1000, 100, 51),
+        ("rwm_mvn_laplace", "mvn_d50", "Laplace", 2.38**2 / 50, 1.0, 800, 100, 52),
+        ("rwm_smvn_normal", "smvn_d20", "Normal", 0.3, 1.0, 800, 100, 53),
+        ("rwm_cube_uniform", "cube_d5", "UniformRadius", 0.4, 1.0, 800, 100, 54),
+        ("rwm_funnel_normal", "funnel_d10", "Normal", 0.2, 1.0, 800, 100, 55),
     ]
     for name, tkey, kind, scale, beta, N, burn, seed in cases:
         t = T[tkey]

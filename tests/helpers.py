@@ -20,6 +20,10 @@ KIND = {
     "HybridRosenbrockTorch": O.TARGET_HYBRID_ROSENBROCK,
     "IIDGammaTorch": O.TARGET_IID_GAMMA,
     "IIDBetaTorch": O.TARGET_IID_BETA,
+    "MultivariateNormalTorch": O.TARGET_DIAG_GAUSSIAN,
+    "ScaledMultivariateNormalTorch": O.TARGET_DIAG_GAUSSIAN,
+    "HypercubeTorch": O.TARGET_HYPERCUBE,
+    "NealFunnelTorch": O.TARGET_NEAL_FUNNEL,
 }
 PROPOSAL_KIND = {"Normal": O.PROPOSAL_NORMAL, "Laplace": O.PROPOSAL_LAPLACE, "UniformRadius": O.PROPOSAL_UNIFORM_RADIUS}
 
@@ -96,6 +100,18 @@ def spec_from_params(cls: str, dim: int, params: dict) -> TargetSpec:
         a, b = g("alpha"), g("beta")
         lnc = f32(dim) * (_lgamma32(a + b) - _lgamma32(a) - _lgamma32(b))
         return TargetSpec(kind, dim, (a, b, lnc), (), None, None, cls, params)
+    if cls == "MultivariateNormalTorch":
+        cov = np.asarray(params["cov"], dtype=np.float64)
+        assert np.count_nonzero(cov - np.diag(np.diag(cov))) == 0
+        return TargetSpec(kind, dim, (g("log_norm_const"),), (0,), g("mean"), (1.0 / np.diag(cov)).astype(f32), cls,
+                          params)
+    if cls == "ScaledMultivariateNormalTorch":
+        return TargetSpec(kind, dim, (g("log_norm_const"),), (1,), g("scaling_factors"), None, cls, params)
+    if kind == O.TARGET_HYPERCUBE:
+        return TargetSpec(kind, dim, (g("left_boundary"), g("right_boundary"), g("log_uniform_density")), (), None, None,
+                          cls, params)
+    if kind == O.TARGET_NEAL_FUNNEL:
+        return TargetSpec(kind, dim, (g("mu_v"), g("sigma_v_sq"), g("mu_z")), (), None, None, cls, params)
     raise KeyError(cls)
 
 

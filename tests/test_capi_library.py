@@ -81,11 +81,11 @@ def test_validation_needs_no_gpu(engine):
     with pytest.raises(engine.PTRWMError):
         engine.ext_raw_per_step(7, 3)
     # variants: every dim 1..104, every target and proposal; nothing beyond
-    for t in range(7):
+    for t in range(10):
         for p in range(3):
             assert all(engine.has_variant(t, p, d) for d in (1, 2, 3, 5, 30, 31, 50, 64, 65, 100, 104))
             assert not engine.has_variant(t, p, 105) and not engine.has_variant(t, p, 0)
-    assert not engine.has_variant(7, 0, 30) and not engine.has_variant(0, 3, 30)
+    assert not engine.has_variant(10, 0, 30) and not engine.has_variant(0, 3, 30)
 
     td, pd, ra = engine.TargetDesc(), engine.ProposalDesc(), engine.RunArgs()
     assert lib.ptrwm_run(None, None, None, None) == -1
@@ -103,7 +103,7 @@ def test_validation_needs_no_gpu(engine):
     assert lib.ptrwm_run(C.byref(td), C.byref(pd), C.byref(ra), None) == -1  # state pointers missing
     td.dim = 105
     assert lib.ptrwm_run(C.byref(td), C.byref(pd), C.byref(ra), None) == -2
-    td.kind, td.dim = 9, 30
+    td.kind, td.dim = 10, 30
     assert lib.ptrwm_logdensity(C.byref(td), None, None, 1, None) == -4
     td.kind, td.dim = 3, 31  # EvenRosenbrock needs an even dim
     assert lib.ptrwm_logdensity(C.byref(td), None, None, 1, None) == -2

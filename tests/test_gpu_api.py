@@ -11,8 +11,10 @@ from algorithms import (ParallelTemperingRWM_GPU_Optimized, RandomWalkMH_GPU_Opt
 from interfaces import MCMCSimulation_GPU
 from oracle import oracle as O
 from proposal_distributions import LaplaceProposal, NormalProposal, UniformRadiusProposal
-from target_distributions import (EvenRosenbrockTorch, FullRosenbrockTorch, HybridRosenbrockTorch, IIDBetaTorch,
-                                  IIDGammaTorch, RoughCarpetDistributionTorch, ThreeMixtureDistributionTorch)
+from target_distributions import (EvenRosenbrockTorch, FullRosenbrockTorch, HybridRosenbrockTorch, HypercubeTorch,
+                                  IIDBetaTorch, IIDGammaTorch, MultivariateNormalTorch, NealFunnelTorch,
+                                  RoughCarpetDistributionTorch, ScaledMultivariateNormalTorch,
+                                  ThreeMixtureDistributionTorch)
 
 pytestmark = pytest.mark.gpu
 
@@ -38,7 +40,19 @@ def test_target_classes_reproduce_reference_log_density(device):
         "gamma_d5": IIDGammaTorch(5, shape=3.5, scale=0.7, device=device),
         "beta_d50": IIDBetaTorch(50, device=device),
         "beta_d5": IIDBetaTorch(5, alpha=1.5, beta=4.0, device=device),
+        "mvn_d50": MultivariateNormalTorch(50, device=device),
+        "mvnd_d8": MultivariateNormalTorch(8, mean=list(np.linspace(-1, 1, 8)),
+                                           cov=np.diag(np.linspace(0.3, 2.5, 8)).tolist(), device=device),
+        "smvn_d20": ScaledMultivariateNormalTorch(20, scaling_factors=G["smvn_d20"][0].params["scaling_factors"],
+                                                  device=device),
+        "cube_d5": HypercubeTorch(5, device=device),
+        "cube2_d3": HypercubeTorch(3, left_boundary=-2.0, right_boundary=1.5, device=device),
+        "funnel_d10": NealFunnelTorch(10, device=device),
+        "funnel_d1": NealFunnelTorch(1, mu_v=0.5, sigma_v_sq=4.0, device=device),
     }
+    with pytest.raises(NotImplementedError, match="non-diagonal"):
+        MultivariateNormalTorch(3, cov=[[1, 0.5, 0], [0.5, 1, 0], [0, 0, 1]], device=device).log_density(
+            torch.zeros(3, device=device))
     for key, t in built.items():
         spec, x, ref, meta = G[key]
         assert t.get_name() == meta["name"]

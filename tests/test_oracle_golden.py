@@ -7,7 +7,8 @@ import helpers as H
 from oracle import oracle as O
 
 TARGET_KEYS = ["rc15_d30", "rc5_d30", "rc4_d20", "rc15s_d10", "tm_d50", "tm15_d30", "tms_d10", "full_d30", "full_d10",
-               "even_d30", "hyb_3_5", "hyb_5_4", "gamma_d50", "gamma_d5", "beta_d50", "beta_d5"]
+               "even_d30", "hyb_3_5", "hyb_5_4", "gamma_d50", "gamma_d5", "beta_d50", "beta_d5",
+               "mvn_d50", "mvnd_d8", "smvn_d20", "cube_d5", "cube2_d3", "funnel_d10", "funnel_d1"]
 
 
 def test_philox_known_answers():
@@ -63,7 +64,8 @@ def test_proposal_transforms_match_reference(tag):
 
 
 RWM_CASES = ["rwm_rc15_normal", "rwm_rc4_normal_beta", "rwm_even_laplace", "rwm_tm_uniform", "rwm_full_normal",
-             "rwm_hyb_laplace", "rwm_gamma_normal", "rwm_beta_uniform", "rwm_rc15s_normal", "rwm_tms_normal"]
+             "rwm_hyb_laplace", "rwm_gamma_normal", "rwm_beta_uniform", "rwm_rc15s_normal", "rwm_tms_normal",
+             "rwm_mvn_laplace", "rwm_smvn_normal", "rwm_cube_uniform", "rwm_funnel_normal"]
 
 
 def rwm_case(name):
