@@ -110,11 +110,24 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
   const long long chain = chain0 + cw;
   const long long rep = chain * T + t;
 
+  // ---- state load: coalesced HBM reads staged through LDS ------------------------------------------------
+  // The wave's live replicas are one contiguous run of n_live * dim floats in `state`.  The wave copies that run
+  // with fully coalesced dword loads (lane i takes elements i, i+64, ...) into its private LDS slab and each lane
+  // then reads its own row (stride dim words: at most a 2-way bank conflict for even dim).  A direct per-lane row
+  // read would touch 64 different cache lines per instruction.  LDS traffic is wave-private: no block barrier.
+  __shared__ float s_stage[kWavesPerBlock][64 * DP];
   float x[DP], y[DP];
   {
-    const float *__restrict__ xp = a.state + rep * D0;
+    float *const sw = s_stage[threadIdx.x >> 6];
+    const long long live_chains = (a.n_chains - chain0 < cpw) ? (a.n_chains - chain0) : cpw;
+    const int stage_total = (int)live_chains * T * D0;  // floats of this wave's run; live lanes are [0, live_chains*T)
+    const float *__restrict__ gs = a.state + chain0 * T * (long long)D0;
+    for (int idx = lane; idx < stage_total; idx += 64) sw[idx] = gs[idx];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float *row = sw + (live ? lane : 0) * D0;  // idle lanes shadow row 0 = replica (chain0, 0)
 #pragma unroll
-    for (int d = 0; d < DP; ++d) x[d] = (d < D0) ? xp[d] : 0.0f;
+    for (int d = 0; d < DP; ++d) x[d] = (d < D0) ? row[d] : 0.0f;
   }
   float lp = a.logp[rep];
   const float beta_t = a.beta[t];
@@ -308,11 +321,30 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     }
   }
 
-  if (live) {
-    float *__restrict__ xp = a.state + rep * D0;
+  // ---- state store: rows -> LDS slab -> coalesced HBM writes -----------------------------------------------
+  {
+    // everything is recomputed from opaque copies so that nothing of the prologue stays live across the step loop
+    const int T2 = fresh_dim<false>(T), D2 = EXACT ? DP : fresh_dim<false>(D0), cpw2 = fresh_dim<false>(cpw);
+    const long long wave2 = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long long c0 = wave2 * cpw2;
+    float *const sw = s_stage[threadIdx.x >> 6];
+    const long long live_chains = (a.n_chains - c0 < cpw2) ? (a.n_chains - c0) : cpw2;
+    const int stage_total = (int)live_chains * T2 * D2;
+    const long long stage_g0 = c0 * T2 * (long long)D2;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (live) {
+      float *row = sw + (threadIdx.x & 63) * D2;
 #pragma unroll
-    for (int d = 0; d < DP; ++d)
-      if (d < D0) xp[d] = x[d];
+      for (int d = 0; d < DP; ++d)
+        if (d < D2) row[d] = x[d];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float *__restrict__ gs = a.state + stage_g0;
+    for (int idx = lane; idx < stage_total; idx += 64) gs[idx] = sw[idx];
+  }
+  if (live) {
     a.logp[rep] = lp;
     if (a.n_accept != nullptr) a.n_accept[rep] += (long long)n_acc;
     if (a.sq_jump != nullptr) a.sq_jump[rep] += sq;
