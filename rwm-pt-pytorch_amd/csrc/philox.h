@@ -30,18 +30,13 @@ constexpr uint32_t kPhiloxW1 = 0xBB67AE85u;
 constexpr uint32_t kStreamMH = 0u;
 constexpr uint32_t kStreamSwap = 1u;
 
-// 32x32 -> 64 multiply by a constant as two full-rate instructions.  hipcc would fuse the pair into one
-// v_mad_u64_u32, which measures 2.8x the issue cost of a full-rate op on gfx950 against 1.0 each for
-// v_mul_hi_u32 / v_mul_lo_u32 (profiles/r01_ubench_valu_costs.txt); the asm keeps them apart.
+// 32x32 -> 64 multiply by a round constant: one v_mad_u64_u32 (both halves, ~7 cycles per wave at 4 waves/SIMD).
+// Splitting it into v_mul_hi_u32 + v_mul_lo_u32 was measured SLOWER (v_mul_lo_u32 is quarter rate: 2.4 + 8.5
+// cycles; whole kernel 7.33 ms vs 6.81 ms, profiles/r01_bench_variants.txt), so the fused form stays.
 __device__ __forceinline__ void mul_hilo(uint32_t m, uint32_t x, uint32_t &hi, uint32_t &lo) {
-#ifdef PTRWM_PHILOX_MAD64
   const uint64_t p = (uint64_t)m * x;
   hi = (uint32_t)(p >> 32);
   lo = (uint32_t)p;
-#else
-  asm("v_mul_hi_u32 %0, %1, %2" : "=v"(hi) : "s"(m), "v"(x));
-  asm("v_mul_lo_u32 %0, %1, %2" : "=v"(lo) : "s"(m), "v"(x));
-#endif
 }
 
 // One Philox4x32-10 block.  The key schedule is wave-uniform (seed only), so the
@@ -52,15 +47,9 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     uint32_t hi0, lo0, hi1, lo1;
-    if (r == 0) {
-      // c0 of the first round is the block index: wave-uniform in the step kernel, so left to the
-      // compiler this product is two SALU multiplies
-      const uint64_t p0 = (uint64_t)kPhiloxM0 * c0;
-      hi0 = (uint32_t)(p0 >> 32);
-      lo0 = (uint32_t)p0;
-    } else {
-      mul_hilo(kPhiloxM0, c0, hi0, lo0);
-    }
+    // (c0 of the first round is the block index: wave-uniform in the step kernel, so the compiler turns that
+    // product into two SALU multiplies)
+    mul_hilo(kPhiloxM0, c0, hi0, lo0);
     mul_hilo(kPhiloxM1, c2, hi1, lo1);
     const uint32_t n0 = hi1 ^ c1 ^ k0;
     const uint32_t n2 = hi0 ^ c3 ^ k1;

@@ -38,6 +38,12 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed) {
         if (OP == 10) a[i] = __umul24(a[i] & 0xffff, 0x1F53) + a[i];
         if (OP == 11) f[i] = __builtin_amdgcn_rcpf(f[i]) + 0.3f;
         if (OP == 12) a[i] = __builtin_amdgcn_ds_bpermute((int)((threadIdx.x * 4 + 4) & 255), (int)a[i]);
+        // mixes: does a transcendental overlap with full-rate work of the SAME wave / of other waves?
+        if (OP == 13) { f[i] = __builtin_amdgcn_exp2f(f[i]); a[i] = (a[i] ^ seed) + 3u; a[i] = (a[i] >> 1) ^ a[i]; a[i] += a[i] >> 3; }
+        if (OP == 14) { a[i] = (a[i] ^ seed) + 3u; a[i] = (a[i] >> 1) ^ a[i]; a[i] += a[i] >> 3; }
+        if (OP == 15) { f[i] = __builtin_amdgcn_exp2f(f[i]); }
+        if (OP == 16) { uint32_t h, l; asm("v_mul_hi_u32 %0, %1, %2" : "=v"(h) : "s"(0xD2511F53u), "v"(a[i])); asm("v_mul_lo_u32 %0, %1, %2" : "=v"(l) : "s"(0xD2511F53u), "v"(a[i])); a[i] = h ^ l; }
+        if (OP == 17) { uint32_t h, l; asm("v_mul_hi_u32 %0, %1, %2" : "=v"(h) : "s"(0xD2511F53u), "v"(a[i])); asm("v_mul_lo_u32 %0, %1, %2" : "=v"(l) : "s"(0xD2511F53u), "v"(a[i])); a[i] = h ^ l; f[i] = __builtin_amdgcn_exp2f(f[i]); }
       }
     }
   }
@@ -107,5 +113,11 @@ int main() {
   run(k<11>, "v_rcp_f32 (+add)", base);
   run(k<12>, "ds_bpermute_b32", base);
   run(kpk, "v_pk_fma_f32 (2 fma)", base);
+  printf("-- mixes (cost per loop body, not per instruction: multiply ns by instructions in the body)\n");
+  run(k<14>, "A: 6 int ops", base);
+  run(k<15>, "B: 1 exp", base);
+  run(k<13>, "A+B in one wave", base);
+  run(k<16>, "C: mul_hi+mul_lo+xor", base);
+  run(k<17>, "C + 1 exp", base);
   return 0;
 }
