@@ -205,13 +205,24 @@ def main():
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
     if rank == 0:
-        traffic = None
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/traffic.json,
+        # FETCH_SIZE/WRITE_SIZE collected in separate passes, FETCH doubled per the gfx950 note); null for other configs
+        traffic, valu = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             with open(tfile) as f:
                 tj = json.load(f)
             key = f"{'rwm' if T == 1 else 'pt'}_d{dim}_T{T}_C{C}_inner{args.inner}" if wl in ("cfg2", "cfg3") else wl
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            rec = tj.get(key, {})
+            traffic = rec.get("hbm_bytes_per_launch")
+            if "valu_insts_per_launch" in rec:
+                # the binding resource: VALU issue.  1024 SIMDs, one wave64 VALU instruction per 2 cycles each.
+                peak = 1024 * rec["shader_clock_ghz"] * 1e9 / 2
+                valu = {"wave_insts_per_wave_step": rec["valu_insts_per_launch"] * 64 / units_per_launch,
+                        "wave_insts_per_s": rec["valu_insts_per_launch"] / (kernel_ms * 1e-3),
+                        "peak_full_rate_wave_insts_per_s": peak,
+                        "issue_frac": rec["valu_insts_per_launch"] / (kernel_ms * 1e-3) / peak,
+                        "source": "SQ_INSTS_VALU / GRBM_GUI_ACTIVE from profiles/r01_pmc_ptrwm_step_kernel_cfg3.csv"}
         out = {
             "metric": "chain-MH-steps/sec", "value": value, "unit": "chain-MH-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -226,7 +237,7 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "kernel": f"ptrwm_step_kernel<{type(target).__name__}, {alg.proposal_dist.get_name()}, dim {dim}, production>",
-                "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes, "valu_issue": valu,
                 "note": "algorithmic bytes = (8*dim+24) B per chain-MH-step (streaming formulation); the fused kernel "
                         "keeps state in registers for the whole launch, so real HBM traffic is ~1/inner of that and "
                         "the kernel is VALU-issue bound, see DESIGN.md",
