@@ -232,9 +232,13 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   const long long n_blocks = (n_waves + kWavesPerBlock - 1) / kWavesPerBlock;
   if (n_blocks > 0x7fffffffll) return PTRWM_E_ARG;
 
-  // One launch covers at most kMaxStepsPerLaunch steps (32-bit in-kernel counters, bounded kernel
-  // run time); longer requests become back-to-back launches on the same stream.
-  const long long kMaxStepsPerLaunch = 1 << 20;
+  // One launch covers a bounded amount of work (32-bit in-kernel counters; no multi-second kernels on a shared
+  // GPU): at most 2^20 steps and about 2^33 chain-steps (~0.3 s at 3e10/s).  Longer requests become back-to-back
+  // launches on the same stream; step0 carries the swap schedule and the RNG position, so the split is invisible.
+  const long long kMaxUnitsPerLaunch = 1ll << 33;
+  long long kMaxStepsPerLaunch = kMaxUnitsPerLaunch / (args->n_chains * (long long)args->n_temps);
+  if (kMaxStepsPerLaunch < 1) kMaxStepsPerLaunch = 1;
+  if (kMaxStepsPerLaunch > (1 << 20)) kMaxStepsPerLaunch = 1 << 20;
   const long long te = args->trace_every > 1 ? args->trace_every : 1;
   k.full.trace_every = (int)te;
   const long long reps = args->n_chains * args->n_temps;

@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
           j2 = fmaf(dl, dl, j2);
           x[d] = acc ? y[d] : x[d];
         }
-        if ((d & 7) == 7) sched_fence();
+        if ((d & 7) == 7) sched_fence_soft();
       }
       if (!acc) j2 = 0.0f;
       lp = lp_mh;
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
           j2 = fmaf(dl, dl, j2);
           x[d] = w;
         }
-        if ((d & 7) == 7) sched_fence();
+        if ((d & 7) == 7) sched_fence_soft();
       }
       lp = my_l;
       ++swap_in_call;

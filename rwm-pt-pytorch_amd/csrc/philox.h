@@ -100,6 +100,12 @@ __device__ __forceinline__ void box_muller(uint32_t ra, uint32_t rb, float &z0, 
 // their consumers and the live set spills to scratch.  A fence every few dimensions keeps the live
 // set at x[] + y[] + one chunk of temporaries; latency is hidden by the 3-6 resident waves per SIMD.
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// fences outside the Philox blocks can be switched off for tuning experiments (PTRWM_FENCE_RNG_ONLY)
+__device__ __forceinline__ void sched_fence_soft() {
+#ifndef PTRWM_FENCE_RNG_ONLY
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 
 // IEEE single ops that the compiler must not contract into an fma: the state
 // update x + scale*z is then bit-identical to the reference's two torch ops.

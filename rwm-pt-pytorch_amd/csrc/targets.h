@@ -64,7 +64,7 @@ struct RoughCarpetT {
         sum_mx += mx;
         prod *= s;
       }
-      if ((d & 3) == 3) sched_fence();
+      if ((d & 3) == 3) sched_fence_soft();
       if ((d & 31) == 31 && d + 1 < DP) {
         lg += hw_log2(prod);
         prod = 1.0f;
@@ -107,7 +107,7 @@ struct ThreeMixture {
         q1 = fmaf(e1, e1, q1);
         q2 = fmaf(e2, e2, q2);
       }
-      if ((d & 7) == 7) sched_fence();
+      if ((d & 7) == 7) sched_fence_soft();
     }
     const float a0 = fmaf(-0.5f, q0, tp.p[0]);
     const float a1 = fmaf(-0.5f, q1, tp.p[1]);
@@ -140,7 +140,7 @@ struct FullRosenbrock {
         s1 = fmaf(b * r, r, s1);
         s2 = fmaf(a * c, c, s2);
       }
-      if ((i & 7) == 7) sched_fence();
+      if ((i & 7) == 7) sched_fence_soft();
     }
     return -(s1 + s2);
   }
@@ -163,7 +163,7 @@ struct EvenRosenbrock {
         s1 = fmaf(a * c, c, s1);
         s2 = fmaf(b * r, r, s2);
       }
-      if ((i & 3) == 3) sched_fence();
+      if ((i & 3) == 3) sched_fence_soft();
     }
     return -(s1 + s2);
   }
@@ -189,7 +189,7 @@ struct HybridRosenbrock {
         const float r = y[i] - parent * parent;
         acc = fmaf(b * r, r, acc);
       }
-      if ((i & 7) == 7) sched_fence();
+      if ((i & 7) == 7) sched_fence_soft();
     }
     return -acc;
   }
@@ -213,7 +213,7 @@ struct IIDGamma {
         bad = bad || (v <= 0.0f);
         acc += fmaf(km1, hw_log2(v), -(v * inv_theta));
       }
-      if ((d & 7) == 7) sched_fence();
+      if ((d & 7) == 7) sched_fence_soft();
     }
     return bad ? kNegInf : acc - tp.p[2];
   }
@@ -237,7 +237,7 @@ struct IIDBeta {
         bad = bad || (v <= 0.0f) || (v >= 1.0f);
         acc += fmaf(am1, hw_log2(v), bm1 * hw_log2(1.0f - v));
       }
-      if ((d & 7) == 7) sched_fence();
+      if ((d & 7) == 7) sched_fence_soft();
     }
     return bad ? kNegInf : acc + tp.p[2];
   }
@@ -262,7 +262,7 @@ struct DiagGaussian {
           q = fmaf(c * tp.vec1[d], c, q);
         }
       }
-      if ((d & 7) == 7) sched_fence();
+      if ((d & 7) == 7) sched_fence_soft();
     }
     return q;
   }
@@ -307,7 +307,7 @@ struct NealFunnel {
         const float c = y[d] - mu_z;
         ss = fmaf(c, c, ss);
       }
-      if ((d & 7) == 7) sched_fence();
+      if ((d & 7) == 7) sched_fence_soft();
     }
     const float dm1 = (float)(D - 1);
     const float lik = -0.5f * dm1 * log_2pi - 0.5f * dm1 * v - 0.5f * hw_exp(-v) * ss;
