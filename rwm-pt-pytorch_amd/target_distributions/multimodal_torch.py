@@ -164,10 +164,12 @@ class RoughCarpetDistributionTorch(TorchTargetDistribution):
         return torch.exp(self.log_density(x))
 
     def density_1d(self, x):
-        """Density of the 1-D three-mode factor at scalar(s) x (plotting helper of the reference, :436-456)."""
+        """Density of the 1-D three-mode factor at scalar(s) x (plotting helper of the reference, :436-456):
+        the dim-1 rough carpet, evaluated by the same engine kernel."""
         x = torch.as_tensor(x, device=self.device, dtype=_F32)
-        z = -0.5 * (x.unsqueeze(-1) - self.modes) ** 2 - self.log_sqrt_2pi + self.log_weights
-        return torch.exp(torch.logsumexp(z, dim=-1))
+        one = ptrwm_hip.Target(ptrwm_hip.TARGET_ROUGH_CARPET, 1,
+                               p=tuple(self.modes.tolist()) + tuple(self.log_weights.tolist()) + (0.0,))
+        return torch.exp(ptrwm_hip.logdensity(one, x.reshape(-1, 1).contiguous())).reshape(x.shape)
 
     def draw_samples_torch(self, n_samples, beta=1.0):
         idx = torch.multinomial(self.weights, n_samples * self.dim, replacement=True).view(n_samples, self.dim)

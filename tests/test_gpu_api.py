@@ -344,3 +344,35 @@ def test_thinned_chain_storage(device):
     for t in range(5):
         assert torch.equal(b.get_all_chains_gpu()[t][1:], a.get_all_chains_gpu()[t][5::5])
     assert a.swap_acceptance_rate == b.swap_acceptance_rate
+
+
+def test_esjd_is_maximised_near_acceptance_0234(device):
+    """End-to-end statistical check of the whole pipeline (RNG, proposal, accept rule, ESJD accumulation) against the
+    classical result the reference's experiments are about: for a product target in high dimension, RWM's ESJD as a
+    function of the proposal scale l (variance l^2/d) peaks near l = 2.38 where the acceptance rate is about 0.234."""
+    dim, chains, steps, burn = 50, 2048, 600, 300
+    target = MultivariateNormalTorch(dim, device=device)
+    np.random.seed(0)
+    ells = [1.2, 1.8, 2.1, 2.4, 2.7, 3.2, 4.0]
+    acc, esjd = [], []
+    for i, ell in enumerate(ells):
+        alg = RandomWalkMH_GPU_Optimized(dim, ell**2 / dim, target, burn_in=burn, device=device, num_chains=chains,
+                                         seed=100 + i)
+        alg._ensure_started()
+        # start in stationarity so the short run measures the stationary ESJD
+        alg._run.state.copy_(torch.randn(chains, 1, dim, device=device))
+        alg._run.logp.copy_(target.log_density(alg._run.state.view(-1, dim)).view(chains, 1))
+        alg._advance(steps + burn)
+        acc.append(alg.acceptance_rate)
+        esjd.append(alg.expected_squared_jump_distance_gpu())
+    assert all(a > b for a, b in zip(acc, acc[1:]))  # acceptance falls monotonically with the scale
+    best = int(np.argmax(esjd))
+    assert ells[best] in (2.1, 2.4, 2.7), (ells[best], esjd)
+    assert 0.18 < acc[best] < 0.32, acc[best]
+    # Roberts-Gelman-Gilks: acceptance at l = 2.38 tends to 0.234 as d grows; at d = 50 it is a little higher
+    assert acc[ells.index(2.4)] == pytest.approx(0.25, abs=0.03)
+    # density_1d of the rough carpet is served by the engine too
+    rc = RoughCarpetDistributionTorch(4, device=device)
+    xs = torch.linspace(-8, 8, 33, device=device)
+    want = sum(w * torch.exp(-0.5 * (xs - m) ** 2) / np.sqrt(2 * np.pi) for w, m in zip([0.5, 0.3, 0.2], [-5.0, 0.0, 5.0]))
+    assert torch.allclose(rc.density_1d(xs), want, rtol=1e-5, atol=1e-7)
