@@ -16,6 +16,13 @@ def pytest_configure(config):
     from oracle import oracle
 
     oracle.lib()
+    # the engine library normally travels pre-built; on a fresh checkout build it (hipcc cross-compiles, ~1 min)
+    import ptrwm_hip
+
+    if not os.path.exists(ptrwm_hip.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
 
 
 def pytest_collection_modifyitems(config, items):
