@@ -9,10 +9,13 @@ namespace ptrwm {
 
 // Exact widths: dims the reference's experiments actually run (data/*dim{2,3,4,5,10,20,30,50,100}*),
 // compiled with dim as a constant.  Generic widths serve every other dim <= 104 with run-time
-// predicates.  X(width, exact)
+// predicates: at widths <= 32 they measure within a few per cent of an exact kernel (dim 29/31/32 vs 30), at
+// widths 40-64 (2 waves/SIMD) about 25 % slower per dimension (dim 41/49 vs 50); a dim that matters can be added
+// to the exact list at build time (profiles/r01_bench_variants.txt).  X(width, exact)
 #define PTRWM_WIDTHS(X) \
   X(2, true) X(3, true) X(4, true) X(5, true) X(10, true) X(20, true) X(30, true) X(50, true) X(100, true) \
-  X(8, false) X(16, false) X(32, false) X(64, false) X(104, false)
+  X(8, false) X(16, false) X(24, false) X(32, false) X(40, false) X(48, false) X(56, false) X(64, false) \
+  X(80, false) X(104, false)
 
 struct WidthInfo {
   int dp;

@@ -83,7 +83,7 @@ def test_validation_needs_no_gpu(engine):
     # variants: every dim 1..104, every target and proposal; nothing beyond
     for t in range(10):
         for p in range(3):
-            assert all(engine.has_variant(t, p, d) for d in (1, 2, 3, 5, 30, 31, 50, 64, 65, 100, 104))
+            assert all(engine.has_variant(t, p, d) for d in (1, 2, 3, 5, 24, 30, 31, 41, 50, 57, 64, 65, 81, 100, 104))
             assert not engine.has_variant(t, p, 105) and not engine.has_variant(t, p, 0)
     assert not engine.has_variant(10, 0, 30) and not engine.has_variant(0, 3, 30)
 

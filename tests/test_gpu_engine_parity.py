@@ -418,7 +418,8 @@ def _ext_arrays(rng, pkind, N, Cn, T, raw):
     return ext
 
 
-ALL_DIMS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 16, 17, 20, 29, 30, 31, 32, 33, 49, 50, 51, 63, 64, 65, 99, 100, 101, 104]
+ALL_DIMS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 16, 17, 20, 23, 24, 25, 29, 30, 31, 32, 33, 40, 41, 48, 49, 50, 51, 56, 57,
+            63, 64, 65, 80, 81, 99, 100, 101, 104]
 
 
 @pytest.mark.parametrize("dim", ALL_DIMS)
