@@ -32,7 +32,7 @@ extern "C" {
 
 #define PTRWM_ABI_VERSION 1
 #define PTRWM_MAX_DIM 104  /* dim-vector lives in VGPRs; widest compiled variant */
-#define PTRWM_MAX_TEMPS 64 /* one ladder must fit one 64-lane wavefront */
+#define PTRWM_MAX_TEMPS 256 /* one ladder lives in one wavefront (<= 64 temps) or one 256-thread workgroup */
 
 /* ---- status codes ------------------------------------------------------ */
 enum {

@@ -48,7 +48,7 @@ class EngineRun:
             raise ValueError("number of replicas must be >= 1")
         n_temps = len(beta_ladder)
         if not 1 <= n_temps <= ptrwm_hip.MAX_TEMPS:
-            raise ValueError(f"the fused kernel keeps one ladder in one wavefront: 1..{ptrwm_hip.MAX_TEMPS} "
+            raise ValueError(f"the fused kernel keeps one ladder inside one workgroup: 1..{ptrwm_hip.MAX_TEMPS} "
                              f"temperatures, got {n_temps}")
         if not 1 <= dim <= ptrwm_hip.MAX_DIM:
             raise ValueError(f"dim must be in 1..{ptrwm_hip.MAX_DIM} for the fused kernel, got {dim}")

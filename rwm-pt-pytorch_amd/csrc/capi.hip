@@ -134,7 +134,7 @@ const char *ptrwm_strerror(int32_t code) {
     case PTRWM_OK: return "ok";
     case PTRWM_E_NULL: return "required pointer is NULL";
     case PTRWM_E_DIM: return "dim out of range or invalid for this target";
-    case PTRWM_E_TEMPS: return "n_temps out of range (1..64)";
+    case PTRWM_E_TEMPS: return "n_temps out of range (1..256)";
     case PTRWM_E_KIND: return "unknown target or proposal kind";
     case PTRWM_E_ARG: return "invalid argument";
     case PTRWM_E_STRUCT: return "struct_size mismatch (ABI version)";
@@ -216,7 +216,8 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   k.swap_every = args->swap_every;
   k.swap_mode = args->swap_mode;
   k.swap_order = args->swap_order;
-  k.chains_per_wave = 64 / args->n_temps;
+  const bool wide = args->n_temps > 64;  // one ladder per 256-thread workgroup
+  k.chains_per_wave = wide ? 1 : 64 / args->n_temps;
   k.k0 = (unsigned)(args->seed & 0xffffffffull);
   k.k1 = (unsigned)(args->seed >> 32);
   k.tp = make_tparams(target);
@@ -229,7 +230,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   k.full.n_raw_ext = ptrwm_ext_raw_per_step(proposal->kind, target->dim);
 
   const long long n_waves = (args->n_chains + k.chains_per_wave - 1) / k.chains_per_wave;
-  const long long n_blocks = (n_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+  const long long n_blocks = wide ? args->n_chains : (n_waves + kWavesPerBlock - 1) / kWavesPerBlock;
   if (n_blocks > 0x7fffffffll) return PTRWM_E_ARG;
 
   // One launch covers a bounded amount of work (32-bit in-kernel counters; no multi-second kernels on a shared

@@ -7,10 +7,11 @@
 // with the replica's dim-vector, log-density and counters held in registers for
 // the whole launch: HBM is touched once to load and once to store the state.
 //
-// Lane map: lane = cw * T + t  (cw = chain slot within the wave, t = temperature),
-// chains_per_wave = 64 / T; lanes >= chains_per_wave*T idle (only when T does
-// not divide 64).  Swaps are therefore pure cross-lane traffic (ds_bpermute),
-// never HBM.
+// Thread map, T <= 64 ("narrow"): lane = cw * T + t (cw = chain slot within the wave, t = temperature),
+// chains_per_wave = 64 / T; lanes >= chains_per_wave*T idle (only when T does not divide 64); the four waves of
+// a workgroup are independent.  64 < T <= 256 ("wide"): one ladder per 256-thread workgroup, t = threadIdx.x.
+// Either way a ladder lives inside one workgroup and swaps go through LDS (broadcast reads of the ladder's
+// log-densities, row exchange through the staging slab), never HBM.
 #pragma once
 #include "philox.h"
 #include "proposals.h"
@@ -74,6 +75,42 @@ __device__ __forceinline__ bool swap_accept_test(float u, float log_prob) {
 //       dim is a wave-uniform run-time value, re-read (opaquely) every step so the compiler tests
 //       `d < dim` with one scalar compare in place instead of hoisting DP booleans into SGPRs.
 // FULL  fixture/trace variant: external randoms, per-step trace and accept-flag outputs.
+// dst[i] = src[i] for i = tid, tid + nthr, ... < total with sixteen independent loads in flight per thread: full
+// chunks unpredicated, then one predicated chunk for the remainder.  (A plain loop waits for every load before
+// issuing the next one when the stride is a run-time value: 1.7x slower for the one-step-per-launch case.)
+__device__ __forceinline__ void stage_copy(float *__restrict__ dst, const float *__restrict__ src, int total, int tid,
+                                           int nthr) {
+  constexpr int kDepth = 16;
+  int i0 = tid;
+  for (; i0 + (kDepth - 1) * nthr < total; i0 += kDepth * nthr) {
+    float v[kDepth];
+#pragma unroll
+    for (int k = 0; k < kDepth; ++k) v[k] = src[i0 + k * nthr];
+#pragma unroll
+    for (int k = 0; k < kDepth; ++k) dst[i0 + k * nthr] = v[k];
+  }
+  if (i0 < total) {
+    float v[kDepth - 1];
+#pragma unroll
+    for (int k = 0; k < kDepth - 1; ++k) {
+      const int i = i0 + k * nthr;
+      v[k] = i < total ? src[i] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < kDepth - 1; ++k) {
+      const int i = i0 + k * nthr;
+      if (i < total) dst[i] = v[k];
+    }
+  }
+}
+
+// the value, re-materialised in a VGPR at this point: stops the compiler from sharing (and keeping live) anything
+// derived from it with code before this point
+__device__ __forceinline__ int opaque_vgpr(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 template <bool EXACT>
 __device__ __forceinline__ int fresh_dim(int d0) {
   if constexpr (!EXACT) asm volatile("" : "+s"(d0));
@@ -96,36 +133,59 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
   const int T = a.n_temps;
   const int D0 = EXACT ? DP : a.dim;
   const int cpw = a.chains_per_wave;
-  const long long wave_id = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const long long chain0 = wave_id * cpw;
-  if (chain0 >= a.n_chains) return;  // wave-uniform
-
-  const int cw_raw = lane / T;
-  const int t_raw = lane - cw_raw * T;
-  const bool live = (cw_raw < cpw) && (chain0 + cw_raw < a.n_chains);
-  // idle lanes shadow replica (chain0, 0): they compute but never store and are never a shuffle source
+  const bool wide = T > 64;  // one ladder per workgroup instead of per wavefront (wave-uniform, grid-uniform)
+  long long chain0;
+  int cw_raw, t_raw;
+  if (wide) {
+    chain0 = blockIdx.x;
+    cw_raw = 0;
+    t_raw = threadIdx.x;
+  } else {
+    chain0 = ((long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * cpw;
+    if (chain0 >= a.n_chains) return;  // wave-uniform; narrow waves never meet at a workgroup barrier
+    cw_raw = lane / T;
+    t_raw = lane - cw_raw * T;
+  }
+  const bool live = wide ? (t_raw < T) : ((cw_raw < cpw) && (chain0 + cw_raw < a.n_chains));
+  // idle threads shadow replica (chain0, 0): they compute but never store and are never an exchange source
   const int cw = live ? cw_raw : 0;
   const int t = live ? t_raw : 0;
-  const int base = cw * T;  // first lane of this lane's ladder
   const long long chain = chain0 + cw;
-  const long long rep = chain * T + t;
+  const int rep_in_group = cw * T + t;  // replica index relative to (chain0, 0)
+  const long long rep = chain0 * T + rep_in_group;
+
+  // ---- LDS ------------------------------------------------------------------------------------------------
+  // s_stage: 256 rows of up to DP floats.  Narrow: each wave owns the slab [wave][64*DP] and packs its live
+  // replicas' rows back to back (row stride = dim).  Wide: the whole array is one slab, row = temperature.
+  // s_l / s_u: per-thread log-density and swap uniform, read back broadcast during a swap sweep.
+  __shared__ float s_stage[kWavesPerBlock][64 * DP];
+  __shared__ float s_l[kBlockThreads];
+  __shared__ float s_u[kBlockThreads];
+  // group-wide ordering of LDS accesses: the ladder's threads are one wave (narrow) or the workgroup (wide)
+  auto sync_group = [&]() {
+    if (wide) {
+      __syncthreads();
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
 
   // ---- state load: coalesced HBM reads staged through LDS ------------------------------------------------
-  // The wave's live replicas are one contiguous run of n_live * dim floats in `state`.  The wave copies that run
-  // with fully coalesced dword loads (lane i takes elements i, i+64, ...) into its private LDS slab and each lane
-  // then reads its own row (stride dim words: at most a 2-way bank conflict for even dim).  A direct per-lane row
-  // read would touch 64 different cache lines per instruction.  LDS traffic is wave-private: no block barrier.
-  __shared__ float s_stage[kWavesPerBlock][64 * DP];
+  // The group's live replicas are one contiguous run of n_live * dim floats in `state`.  The group copies that
+  // run with fully coalesced dword loads (thread i takes elements i, i+n, ...) into its slab and each thread then
+  // reads its own row (stride dim words: at most a 2-way bank conflict for even dim).  A direct per-thread row
+  // read would touch 64 different cache lines per instruction.
   float x[DP], y[DP];
   {
-    float *const sw = s_stage[threadIdx.x >> 6];
-    const long long live_chains = (a.n_chains - chain0 < cpw) ? (a.n_chains - chain0) : cpw;
-    const int stage_total = (int)live_chains * T * D0;  // floats of this wave's run; live lanes are [0, live_chains*T)
+    const long long live_chains = wide ? 1 : ((a.n_chains - chain0 < cpw) ? (a.n_chains - chain0) : cpw);
+    const int stage_total = (int)live_chains * T * D0;  // floats of this group's run
     const float *__restrict__ gs = a.state + chain0 * T * (long long)D0;
-    for (int idx = lane; idx < stage_total; idx += 64) sw[idx] = gs[idx];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const float *row = sw + (live ? lane : 0) * D0;  // idle lanes shadow row 0 = replica (chain0, 0)
+    float *const slab = wide ? &s_stage[0][0] : s_stage[threadIdx.x >> 6];
+    const int nthr = wide ? kBlockThreads : 64, tid = wide ? (int)threadIdx.x : lane;
+    stage_copy(slab, gs, stage_total, tid, nthr);
+    sync_group();
+    const float *row = slab + (live ? tid : 0) * D0;  // idle threads shadow row 0 = replica (chain0, 0)
 #pragma unroll
     for (int d = 0; d < DP; ++d) x[d] = (d < D0) ? row[d] : 0.0f;
   }
@@ -204,10 +264,17 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       lp = lp_mh;
     } else {
       // ---- temperature swaps on the post-MH log-densities (pt_rwm_gpu_optimized.py:594-633) ----
-      // src = lane whose post-MH vector ends up at this lane's temperature
-      int src = lane;
+      // The exchange indices are rebuilt here from an opaque copy of threadIdx.x, so that none of them occupies a
+      // register (or a scratch slot) across the MH part of the step.
+      const int slot = opaque_vgpr((int)threadIdx.x);           // this thread's slot in s_l / s_u
+      const int slab_slot0 = wide ? 0 : (slot & ~63);            // first slot of this thread's slab
+      const int row_in_slab = slot - slab_slot0;
+      const int base = live ? slot - t : slab_slot0;             // slot of temperature 0 of this thread's ladder
+      float *const slab = &s_stage[0][0] + (wide ? 0 : (slot >> 6) * (64 * DP));
+      // src = slot whose post-MH vector ends up at this thread's temperature
+      int src = slot;
       float my_l = lp_mh;
-      bool pair_acc = false;  // did pair (t, t+1) accept (recorded on lane t)
+      bool pair_acc = false;  // did pair (t, t+1) accept (recorded on the thread of temperature t)
       float us;
       if (ext) {
         us = (t < T - 1) ? a.full.ext_swap_u[((long long)swap_in_call * a.n_chains + chain) * (T - 1) + t] : 2.0f;
@@ -215,18 +282,21 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
         const u32x4 r = philox4x32_10(rc.c0hi, rc.c1, rc.c2, c3_base | (kStreamSwap << 8), rc.k0, rc.k1);
         us = u01(r.x);
       }
+      // publish this thread's log-density and swap uniform; the sweep reads them back with broadcast ds_reads
+      s_l[slot] = my_l;
+      s_u[slot] = us;
+      sync_group();
       if (a.swap_order == PTRWM_ORDER_SEQUENTIAL) {
         if (a.swap_mode == PTRWM_SWAP_EXCHANGE) {
-          // The sweep j = 0..T-2 carries one state upward: at pair j the state now
-          // at position j (carried) meets the still-untouched state of position j+1.
-          // Every lane of the ladder replays the scan from the original values
-          // (no dependent shuffles) and keeps what lands on its own position.
-          float car_l = __shfl(my_l, base, 64);
+          // The sweep j = 0..T-2 carries one state upward: at pair j the state now at position j (carried) meets
+          // the still-untouched state of position j+1.  Every thread of the ladder replays the scan from the
+          // published original values (uniform addresses: LDS broadcasts, no dependent cross-lane traffic) and
+          // keeps what lands on its own position.
+          float car_l = s_l[base];
           int car_i = base;
-          const float l_own = my_l;
           for (int j = 0; j < T - 1; ++j) {
-            const float lk = __shfl(l_own, base + j + 1, 64);
-            const float u = __shfl(us, base + j, 64);
+            const float lk = s_l[base + j + 1];
+            const float u = s_u[base + j];
             const float bj = a.beta[j], bk = a.beta[j + 1];
             const bool ok = swap_accept_test(u, swap_log_prob(bj, bk, car_l, lk));
             const int ik = base + j + 1;
@@ -245,14 +315,14 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
             src = car_i;
           }
         } else {
-          // reference_copy: row j <- row k, row k untouched, so every pair compares
-          // the original rows j and j+1: no carried state, fully parallel.
-          const float lk = __shfl(my_l, lane + 1, 64);
+          // reference_copy: row j <- row k, row k untouched, so every pair compares the original rows j and j+1:
+          // no carried state, fully parallel.
           if (t < T - 1) {
+            const float lk = s_l[slot + 1];
             const bool ok = swap_accept_test(us, swap_log_prob(beta_t, a.beta[t + 1], my_l, lk));
             if (ok) {
               my_l = lk;
-              src = lane + 1;
+              src = slot + 1;
             }
             pair_acc = ok;
           }
@@ -260,13 +330,13 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       } else {
         // even/odd: event n attempts the disjoint pairs (j, j+1) with j == n (mod 2)
         const int par = (ev_par0 + swap_in_call) & 1;
-        const bool lower = ((t & 1) == par);          // this lane is the lower index j of its pair
+        const bool lower = ((t & 1) == par);          // this thread is the lower index j of its pair
         const int partner_t = lower ? t + 1 : t - 1;
         const bool valid = partner_t >= 0 && partner_t < T;
-        const int partner = base + (valid ? partner_t : t);
-        const float l_other = __shfl(my_l, partner, 64);
-        const float u_low = __shfl(us, lower ? lane : partner, 64);
         if (valid) {
+          const int partner = base + partner_t;
+          const float l_other = s_l[partner];
+          const float u_low = lower ? us : s_u[partner];
           const int tj = lower ? t : partner_t;
           const float lj = lower ? my_l : l_other;
           const float lk = lower ? l_other : my_l;
@@ -282,17 +352,26 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
         ++n_swap_acc;
         last_event = swap_in_call;
       }
-      // commit MH move and swap in one pass: fetch the post-MH vector of lane `src`
+      // commit MH move and swap in one pass: every thread publishes its post-MH vector as its slab row, then
+      // fetches the row of slot `src` (rows exchanged through LDS: 2 LDS ops per dimension, no HBM)
+      {
+        float *my_row = slab + row_in_slab * D;
 #pragma unroll
-      for (int d = 0; d < DP; ++d) {
-        if (d < D) {
-          const float v = acc ? y[d] : x[d];
-          const float w = __shfl(v, src, 64);
-          const float dl = sub_rn(w, x[d]);
-          j2 = fmaf(dl, dl, j2);
-          x[d] = w;
+        for (int d = 0; d < DP; ++d)
+          if (d < D) my_row[d] = acc ? y[d] : x[d];
+        sync_group();
+        const int Dr = fresh_dim<EXACT>(D0);  // generic widths: fresh d < dim compares instead of 2*DP live masks
+        const float *src_row = slab + (src - slab_slot0) * Dr;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) {
+          if (d < Dr) {
+            const float w = src_row[d];
+            const float dl = sub_rn(w, x[d]);
+            j2 = fmaf(dl, dl, j2);
+            x[d] = w;
+          }
+          if ((d & 7) == 7) sched_fence_soft();
         }
-        if ((d & 7) == 7) sched_fence_soft();
       }
       lp = my_l;
       ++swap_in_call;
@@ -322,29 +401,31 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
   }
 
   // ---- state store: rows -> LDS slab -> coalesced HBM writes -----------------------------------------------
+  long long c0_out;
   {
     // everything is recomputed from opaque copies so that nothing of the prologue stays live across the step loop
     const int T2 = fresh_dim<false>(T), D2 = EXACT ? DP : fresh_dim<false>(D0), cpw2 = fresh_dim<false>(cpw);
-    const long long wave2 = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const long long c0 = wave2 * cpw2;
-    float *const sw = s_stage[threadIdx.x >> 6];
-    const long long live_chains = (a.n_chains - c0 < cpw2) ? (a.n_chains - c0) : cpw2;
+    const bool wide2 = T2 > 64;
+    const long long c0 = wide2 ? (long long)blockIdx.x : ((long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * cpw2;
+    float *const slab2 = wide2 ? &s_stage[0][0] : s_stage[threadIdx.x >> 6];
+    const long long live_chains = wide2 ? 1 : ((a.n_chains - c0 < cpw2) ? (a.n_chains - c0) : cpw2);
     const int stage_total = (int)live_chains * T2 * D2;
     const long long stage_g0 = c0 * T2 * (long long)D2;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    c0_out = c0;
+    sync_group();  // the last swap's row reads are done before the rows are overwritten
     if (live) {
-      float *row = sw + (threadIdx.x & 63) * D2;
+      float *row = slab2 + (wide2 ? (int)threadIdx.x : (int)(threadIdx.x & 63)) * D2;
 #pragma unroll
       for (int d = 0; d < DP; ++d)
         if (d < D2) row[d] = x[d];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    sync_group();
     float *__restrict__ gs = a.state + stage_g0;
-    for (int idx = lane; idx < stage_total; idx += 64) gs[idx] = sw[idx];
+    const int nthr = wide2 ? kBlockThreads : 64, tid = wide2 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    stage_copy(gs, slab2, stage_total, tid, nthr);
   }
   if (live) {
+    const long long rep = c0_out * fresh_dim<false>(T) + opaque_vgpr(rep_in_group);
     a.logp[rep] = lp;
     if (a.n_accept != nullptr) a.n_accept[rep] += (long long)n_acc;
     if (a.sq_jump != nullptr) a.sq_jump[rep] += sq;

@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("PTRWM_LIB") or os.path.join(os.path.dirname(_HERE), "
 
 ABI_VERSION = 1
 MAX_DIM = 104
-MAX_TEMPS = 64
+MAX_TEMPS = 256
 
 # target kinds (include/ptrwm.h)
 TARGET_ROUGH_CARPET = 0

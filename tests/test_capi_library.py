@@ -93,7 +93,7 @@ def test_validation_needs_no_gpu(engine):
     ra.struct_size = 4
     assert lib.ptrwm_run(C.byref(td), C.byref(pd), C.byref(ra), None) == -6  # struct size / ABI mismatch
     ra.struct_size = C.sizeof(engine.RunArgs)
-    ra.n_temps, ra.swap_every = 65, 1
+    ra.n_temps, ra.swap_every = 257, 1
     assert lib.ptrwm_run(C.byref(td), C.byref(pd), C.byref(ra), None) == -3  # too many temperatures
     ra.n_temps, ra.swap_every = 4, 0
     assert lib.ptrwm_run(C.byref(td), C.byref(pd), C.byref(ra), None) == -5

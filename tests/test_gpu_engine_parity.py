@@ -506,21 +506,24 @@ def test_generic_width_targets_vs_oracle(device, cls, dim, params, pkind):
         assert np.array_equal(got["n_accept"], want["n_accept"]) and np.array_equal(got["swap_accept"], want["swap_accept"])
 
 
-@pytest.mark.parametrize("T,Cn", [(64, 3), (33, 2), (63, 5), (21, 4), (2, 100), (1, 1), (32, 1)])
+@pytest.mark.parametrize("T,Cn", [(64, 3), (33, 2), (63, 5), (21, 4), (2, 100), (1, 1), (32, 1),
+                                  (65, 2), (100, 3), (128, 1), (200, 2), (256, 2)])  # > 64: one ladder per workgroup
 def test_ladder_shapes_vs_oracle(device, T, Cn):
-    """Ladders that fill a wavefront exactly, leave idle lanes (T not dividing 64), or span several waves."""
+    """Ladders that fill a wavefront exactly, leave idle lanes (T not dividing 64), span several waves, or are
+    wider than a wavefront (one ladder per 256-thread workgroup, exchange through LDS with workgroup barriers)."""
     spec = H.target_spec("rc15_d30")
     beta = (0.02 ** (np.arange(T) / max(1, T - 1))).astype(np.float32)
     prop = H.proposal_spec("Normal", 30, beta, base_variance_scalar=2.38**2 / 30)
     rng = np.random.default_rng(T * 1000 + Cn)
     st, lp = start_state(spec, Cn, T, rng)
     N = 40
-    for order in ("sequential", "even_odd"):
+    for order, mode in (("sequential", "exchange"), ("even_odd", "exchange"), ("sequential", "reference_copy"),
+                        ("even_odd", "reference_copy")):
         kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=2, swap_every=3,
                   ext_prop=rng.standard_normal((N, Cn, T, 30)).astype(np.float32),
                   ext_u=rng.random((N, Cn, T)).astype(np.float32),
                   ext_swap_u=rng.random((N // 3, Cn, T - 1)).astype(np.float32) if T > 1 else None,
-                  swap_order=E.SWAP_ORDERS[order], want_flags=True)
+                  swap_order=E.SWAP_ORDERS[order], swap_mode=E.SWAP_MODES[mode], want_flags=True)
         want = O.run(spec.oracle(), prop.oracle(), trace_chains=Cn, trace_temps=T, **kw)
         got = gpu_run(spec, prop, device, trace_temps=T, **kw)
         first = H.first_mismatch(got["accept_flags"], want["accept_flags"])
@@ -529,7 +532,7 @@ def test_ladder_shapes_vs_oracle(device, T, Cn):
         assert np.array_equal(got["trace"][:upto], want["trace"][:upto])
         if first is None:
             for k in ("n_accept", "swap_accept", "last_swap_ordinal"):
-                assert np.array_equal(got[k], want[k]), (k, order)
+                assert np.array_equal(got[k], want[k]), (k, order, mode)
 
 
 def test_zero_chains_and_support_edges(device):

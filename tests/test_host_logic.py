@@ -208,8 +208,8 @@ def test_pt_constructor_contract_and_ladders():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         b.step()
     # more temperatures than a wavefront holds is refused, not silently truncated
-    c = ParallelTemperingRWM_GPU_Optimized(6, 0.3, t, beta_ladder=[0.99**i for i in range(65)], device="cpu")
-    with pytest.raises(ValueError, match="one wavefront"):
+    c = ParallelTemperingRWM_GPU_Optimized(6, 0.3, t, beta_ladder=[0.99**i for i in range(257)], device="cpu")
+    with pytest.raises(ValueError, match="one workgroup"):
         c.step()
     with pytest.warns(UserWarning, match="float32"):
         ParallelTemperingRWM_GPU_Optimized(6, 0.3, t, beta_ladder=[1.0, 0.5], device="cpu", dtype=torch.float64)
