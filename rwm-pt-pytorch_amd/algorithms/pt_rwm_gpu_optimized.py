@@ -380,7 +380,7 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
             "parallel_processing": f"{self.num_chains} temperatures x {self.num_replicas} replicas, one thread each",
             "batch_matrix_multiply": "diagonal Cholesky folded into a per-temperature scale (no bmm)",
             "precomputed_randoms": "none: Philox4x32-10 drawn in-kernel",
-            "clone_free_swaps": "swaps are cross-lane permutes inside one wavefront (no HBM traffic)",
+            "clone_free_swaps": "swaps are LDS exchanges inside one wavefront / workgroup (no HBM traffic)",
             "kernel_fusion": "proposal, log-density, accept, update, swaps and statistics in one HIP kernel",
             "memory_allocated_mb": torch.cuda.memory_allocated() / 1e6 if self.device.type == "cuda" else 0,
         }
