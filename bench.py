@@ -224,6 +224,21 @@ def main():
         elapsed = float(t.item())
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
+    # HBM copy probe (the measured copy bandwidth as a second denominator): 1 GiB device-to-device
+    copy_gbps = None
+    if rank == 0:
+        src = torch.empty(1 << 28, device=dev, dtype=torch.float32).normal_()
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 10 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+
     summary = allreduce_summary(run.summary(), coll_dev)  # the only collective: whole-job acceptance / ESJD
     units_per_launch = C * T * args.inner            # per GPU
     value = world * units_per_launch * args.steps / elapsed
@@ -264,6 +279,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "kernel": f"ptrwm_step_kernel<{type(target).__name__}, {alg.proposal_dist.get_name()}, dim {dim}, production>",
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes, "valu_issue": valu,
+                "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
                 "note": "algorithmic bytes = (8*dim+24) B per chain-MH-step (streaming formulation); the fused kernel "
                         "keeps state in registers for the whole launch, so real HBM traffic is ~1/inner of that and "
                         "the kernel is VALU-issue bound, see DESIGN.md",

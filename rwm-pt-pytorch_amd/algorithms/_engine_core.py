@@ -77,6 +77,13 @@ class EngineRun:
         self.sq_jump = torch.zeros(shape, device=device, dtype=torch.float64)
         self.swap_accept = torch.zeros(shape, device=device, dtype=torch.int64)
         self.last_ord = torch.zeros(shape, device=device, dtype=torch.int64)
+        # everything ptrwm_run needs that stays fixed for this run, marshalled once (the tensors above are never
+        # re-allocated: the kernel updates them in place)
+        self._plan = ptrwm_hip.RunPlan(
+            self.target, self.proposal, state=self.state, logp=self.logp, beta=self.beta, burn_in=self.burn_in,
+            swap_every=self.swap_every, swap_mode=self.swap_mode, swap_order=self.swap_order, seed=self.seed,
+            chain_offset=self.chain_offset, n_accept=self.n_accept, sq_jump=self.sq_jump,
+            swap_accept=self.swap_accept, last_swap_ordinal=self.last_ord)
 
     # ---- stepping ---------------------------------------------------------------------------
     def traced_rows(self, n_steps: int, every: int) -> int:
@@ -88,13 +95,11 @@ class EngineRun:
         """Enqueue n_steps fused steps (no host synchronisation)."""
         if n_steps <= 0:
             return
-        ptrwm_hip.run(
-            self.target, self.proposal, state=self.state, logp=self.logp, beta=self.beta, step0=self.steps_done,
-            n_steps=n_steps, burn_in=self.burn_in, swap_every=self.swap_every, swap_mode=self.swap_mode,
-            swap_order=self.swap_order, seed=self.seed, chain_offset=self.chain_offset, n_accept=self.n_accept,
-            sq_jump=self.sq_jump, swap_accept=self.swap_accept, last_swap_ordinal=self.last_ord, trace=trace,
-            trace_logp=trace_logp, trace_row0=trace_row0, trace_every=trace_every,
-        )
+        if trace is None and trace_logp is None:
+            self._plan.launch(self.steps_done, n_steps)
+        else:
+            self._plan.launch(self.steps_done, n_steps, trace=trace, trace_logp=trace_logp, trace_row0=trace_row0,
+                              trace_every=trace_every)
         self.steps_done += n_steps
 
     # ---- summaries (each read synchronises) ---------------------------------------------------

@@ -50,30 +50,42 @@ static int check_target(const ptrwm_target_desc *t) {
   return PTRWM_OK;
 }
 
-// RoughCarpet: is the smallest of the three per-dimension mixture terms always < 2^-26 of the largest?
-// g(x) = max_k a_k(x) - min_k a_k(x) in log2 units, a_k = -0.5 log2(e) (x - m_k)^2 + log2 w_k.  Outside
-// [min m - 1, max m + 1] g grows linearly, so a grid over that interval bounds it.
+// RoughCarpet: is the smallest of the three per-dimension mixture terms always < 2^-27 of the largest?
+// In log2 units a_k(x) = -0.5 log2(e) (x - m_k)^2 + log2 w_k; the three parabolas share their curvature, so every
+// difference a_j - a_k is LINEAR in x and g(x) = max_k a_k - min_k a_k is the maximum of six lines: convex and
+// piecewise linear.  Its minimum over the real line is therefore attained where two of the lines cross (or g is
+// constant), so checking the (at most 15) crossings is exact.  A few dozen flops: this runs on every ptrwm_run.
 static bool rough_carpet_two_term(const float *p) {
   const double l2e = 1.4426950408889634;
-  double lo = p[0], hi = p[0];
-  for (int k = 1; k < 3; ++k) {
-    lo = p[k] < lo ? p[k] : lo;
-    hi = p[k] > hi ? p[k] : hi;
-  }
-  lo -= 1.0;
-  hi += 1.0;
-  const int n = 40000;
-  for (int i = 0; i <= n; ++i) {
-    const double x = lo + (hi - lo) * i / n;
-    double amax = -1e300, amin = 1e300;
+  double sl[6], ic[6];  // line i: sl[i] * x + ic[i]
+  int n = 0;
+  for (int j = 0; j < 3; ++j)
     for (int k = 0; k < 3; ++k) {
-      const double a = (-0.5 * (x - p[k]) * (x - p[k]) + p[3 + k]) * l2e;
-      amax = a > amax ? a : amax;
-      amin = a < amin ? a : amin;
+      if (j == k) continue;
+      const double mj = p[j], mk = p[k];
+      sl[n] = l2e * (mj - mk);
+      ic[n] = l2e * (-0.5 * (mj * mj - mk * mk) + ((double)p[3 + j] - (double)p[3 + k]));
+      if (!(sl[n] == sl[n]) || !(ic[n] == ic[n])) return false;  // NaN parameters
+      ++n;
     }
-    if (!(amax - amin > 27.0)) return false;  // also false for NaN parameters
-  }
-  return true;
+  auto g = [&](double x) {
+    double v = -1e300;
+    for (int i = 0; i < 6; ++i) {
+      const double y = sl[i] * x + ic[i];
+      v = y > v ? y : v;
+    }
+    return v;
+  };
+  double gmin = g(0.0);  // covers the all-slopes-equal (constant) case
+  for (int i = 0; i < 6; ++i)
+    for (int j = i + 1; j < 6; ++j) {
+      if (sl[i] == sl[j]) continue;
+      const double x = (ic[j] - ic[i]) / (sl[i] - sl[j]);
+      if (!(x == x) || x > 1e30 || x < -1e30) continue;
+      const double v = g(x);
+      gmin = v < gmin ? v : gmin;
+    }
+  return gmin > 27.0;
 }
 
 static TParams make_tparams(const ptrwm_target_desc *t) {

@@ -19,7 +19,10 @@
 
 namespace ptrwm {
 
-constexpr int kBlockThreads = 256;
+#ifndef PTRWM_BLOCK_THREADS
+#define PTRWM_BLOCK_THREADS 256
+#endif
+constexpr int kBlockThreads = PTRWM_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 
 // Arguments only the fixture / trace variant of the kernel (FULL = true) reads.  Keeping them out

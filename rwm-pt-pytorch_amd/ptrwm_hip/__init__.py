@@ -276,6 +276,123 @@ def philox_raw(seed: int, c0: int, c1: int, c2: int, c3: int, n: int, device) ->
     return out.to(torch.int64) & 0xFFFFFFFF
 
 
+class RunPlan:
+    """The arguments of ``ptrwm_run`` that do not change between launches of one sampler run, validated and
+    marshalled once.  ``launch`` only fills in the step range, the optional trace / fixture buffers and the
+    current stream, so a one-step launch costs a few microseconds of host time (the reference's per-step
+    ``step()`` calling pattern stays launch-bound on the kernel, not on Python).  The plan holds references to
+    its tensors, so the device pointers stay valid for as long as the plan lives."""
+
+    def __init__(
+        self,
+        target: Target,
+        proposal: Proposal,
+        *,
+        state: torch.Tensor,  # [C, T, D] float32
+        logp: torch.Tensor,  # [C, T] float32
+        beta: torch.Tensor,  # [T] float32
+        burn_in: int = 0,
+        swap_every: int = 1,
+        swap_mode: int = SWAP_EXCHANGE,
+        swap_order: int = ORDER_SEQUENTIAL,
+        seed: int = 0,
+        chain_offset: int = 0,
+        n_accept: Optional[torch.Tensor] = None,  # [C, T] int64
+        sq_jump: Optional[torch.Tensor] = None,  # [C, T] float64
+        swap_accept: Optional[torch.Tensor] = None,  # [C, T] int64
+        last_swap_ordinal: Optional[torch.Tensor] = None,  # [C, T] int64
+    ):
+        self._lib = load_library()
+        if state.dim() != 3:
+            raise ValueError("state must be [n_chains, n_temps, dim]")
+        Cn, T, D = state.shape
+        if D != target.dim:
+            raise ValueError(f"state dim {D} != target dim {target.dim}")
+        if tuple(logp.shape) != (Cn, T) or beta.numel() != T or proposal.temp_scale.numel() != T:
+            raise ValueError("logp/beta/temp_scale shapes do not match state")
+        self.shape = (Cn, T, D)
+        self.proposal_kind = proposal.kind
+        self.device = state.device
+        a = RunArgs()
+        a.struct_size = C.sizeof(RunArgs)
+        a.n_temps = T
+        a.n_chains = Cn
+        a.chain_offset = chain_offset
+        a.state = _require_device(state, "state", torch.float32)
+        a.logp = _require_device(logp, "logp", torch.float32)
+        a.beta = _require_device(beta, "beta", torch.float32)
+        for name, t, dt in (
+            ("n_accept", n_accept, torch.int64),
+            ("sq_jump", sq_jump, torch.float64),
+            ("swap_accept", swap_accept, torch.int64),
+            ("last_swap_ordinal", last_swap_ordinal, torch.int64),
+        ):
+            if t is not None and tuple(t.shape) != (Cn, T):
+                raise ValueError(f"{name} must have shape [{Cn}, {T}]")
+            setattr(a, name, _opt(t, name, dt))
+        a.burn_in = burn_in
+        a.swap_every = swap_every
+        a.swap_mode = swap_mode
+        a.swap_order = swap_order
+        a.seed = seed & (2**64 - 1)
+        self._a = a
+        self._t = target.desc()
+        self._p = proposal.desc()
+        self._refs = (self._t, self._p, C.byref(self._t), C.byref(self._p), C.byref(a))
+        self._keep = (target, proposal, state, logp, beta, n_accept, sq_jump, swap_accept, last_swap_ordinal)
+        self._plain = True  # no per-launch buffers set in _a
+
+    def launch(
+        self,
+        step0: int,
+        n_steps: int,
+        *,
+        ext_prop: Optional[torch.Tensor] = None,
+        ext_u: Optional[torch.Tensor] = None,
+        ext_swap_u: Optional[torch.Tensor] = None,
+        trace: Optional[torch.Tensor] = None,  # [rows, trace_chains, trace_temps, D]
+        trace_logp: Optional[torch.Tensor] = None,
+        trace_row0: int = 0,
+        trace_every: int = 1,
+        accept_flags: Optional[torch.Tensor] = None,  # [n_steps, C, T] uint8
+    ) -> None:
+        """Enqueue ``n_steps`` fused MH(+swap) steps, starting at global step ``step0``, on the current stream."""
+        a = self._a
+        a.step0 = step0
+        a.n_steps = n_steps
+        plain = (ext_prop is None and ext_u is None and ext_swap_u is None and trace is None and trace_logp is None
+                 and accept_flags is None)
+        if not (plain and self._plain):
+            Cn, T, D = self.shape
+            a.ext_prop = _opt(ext_prop, "ext_prop", torch.float32)
+            a.ext_u = _opt(ext_u, "ext_u", torch.float32)
+            a.ext_swap_u = _opt(ext_swap_u, "ext_swap_u", torch.float32)
+            if ext_prop is not None:
+                raw = ext_raw_per_step(self.proposal_kind, D)
+                if (tuple(ext_prop.shape) != (n_steps, Cn, T, raw) or ext_u is None
+                        or tuple(ext_u.shape) != (n_steps, Cn, T)):
+                    raise ValueError("ext_prop/ext_u shapes do not match [n_steps, n_chains, n_temps, raw]")
+            a.trace = _opt(trace, "trace", torch.float32)
+            a.trace_logp = _opt(trace_logp, "trace_logp", torch.float32)
+            a.trace_every, a.trace_chains, a.trace_temps = 0, 0, 0
+            if trace is not None:
+                te = max(1, int(trace_every))
+                rows = (step0 + n_steps) // te - step0 // te  # steps of this call whose step_counter is a multiple of te
+                if trace.dim() != 4 or trace.shape[3] != D or trace.shape[0] < trace_row0 + rows:
+                    raise ValueError("trace must be [rows >= trace_row0 + traced steps, trace_chains, trace_temps, dim]")
+                a.trace_every = te
+                a.trace_chains = trace.shape[1]
+                a.trace_temps = trace.shape[2]
+            a.trace_row0 = trace_row0
+            if accept_flags is not None and tuple(accept_flags.shape) != (n_steps, Cn, T):
+                raise ValueError("accept_flags must be [n_steps, n_chains, n_temps]")
+            a.accept_flags = _opt(accept_flags, "accept_flags", torch.uint8)
+            self._plain = plain
+        rc = self._lib.ptrwm_run(self._refs[2], self._refs[3], self._refs[4], _stream(self.device))
+        if rc != 0:
+            raise PTRWMError(rc, "ptrwm_run")
+
+
 def run(
     target: Target,
     proposal: Proposal,
@@ -295,71 +412,11 @@ def run(
     sq_jump: Optional[torch.Tensor] = None,  # [C, T] float64
     swap_accept: Optional[torch.Tensor] = None,  # [C, T] int64
     last_swap_ordinal: Optional[torch.Tensor] = None,  # [C, T] int64
-    ext_prop: Optional[torch.Tensor] = None,
-    ext_u: Optional[torch.Tensor] = None,
-    ext_swap_u: Optional[torch.Tensor] = None,
-    trace: Optional[torch.Tensor] = None,  # [rows, trace_chains, trace_temps, D]
-    trace_logp: Optional[torch.Tensor] = None,
-    trace_row0: int = 0,
-    trace_every: int = 1,
-    accept_flags: Optional[torch.Tensor] = None,  # [n_steps, C, T] uint8
+    **per_launch,
 ) -> None:
-    """Enqueue ``n_steps`` fused MH(+swap) steps for every (chain, temperature) replica."""
-    lib = load_library()
-    if state.dim() != 3:
-        raise ValueError("state must be [n_chains, n_temps, dim]")
-    Cn, T, D = state.shape
-    if D != target.dim:
-        raise ValueError(f"state dim {D} != target dim {target.dim}")
-    if tuple(logp.shape) != (Cn, T) or beta.numel() != T or proposal.temp_scale.numel() != T:
-        raise ValueError("logp/beta/temp_scale shapes do not match state")
-    a = RunArgs()
-    a.struct_size = C.sizeof(RunArgs)
-    a.n_temps = T
-    a.n_chains = Cn
-    a.chain_offset = chain_offset
-    a.state = _require_device(state, "state", torch.float32)
-    a.logp = _require_device(logp, "logp", torch.float32)
-    a.beta = _require_device(beta, "beta", torch.float32)
-    for name, t, dt in (
-        ("n_accept", n_accept, torch.int64),
-        ("sq_jump", sq_jump, torch.float64),
-        ("swap_accept", swap_accept, torch.int64),
-        ("last_swap_ordinal", last_swap_ordinal, torch.int64),
-    ):
-        if t is not None and tuple(t.shape) != (Cn, T):
-            raise ValueError(f"{name} must have shape [{Cn}, {T}]")
-        setattr(a, name, _opt(t, name, dt))
-    a.step0 = step0
-    a.n_steps = n_steps
-    a.burn_in = burn_in
-    a.swap_every = swap_every
-    a.swap_mode = swap_mode
-    a.swap_order = swap_order
-    a.seed = seed & (2**64 - 1)
-    a.ext_prop = _opt(ext_prop, "ext_prop", torch.float32)
-    a.ext_u = _opt(ext_u, "ext_u", torch.float32)
-    a.ext_swap_u = _opt(ext_swap_u, "ext_swap_u", torch.float32)
-    if ext_prop is not None:
-        raw = ext_raw_per_step(proposal.kind, D)
-        if tuple(ext_prop.shape) != (n_steps, Cn, T, raw) or ext_u is None or tuple(ext_u.shape) != (n_steps, Cn, T):
-            raise ValueError("ext_prop/ext_u shapes do not match [n_steps, n_chains, n_temps, raw]")
-    a.trace = _opt(trace, "trace", torch.float32)
-    a.trace_logp = _opt(trace_logp, "trace_logp", torch.float32)
-    if trace is not None:
-        te = max(1, int(trace_every))
-        rows = (step0 + n_steps) // te - step0 // te  # steps of this call whose step_counter is a multiple of te
-        if trace.dim() != 4 or trace.shape[3] != D or trace.shape[0] < trace_row0 + rows:
-            raise ValueError("trace must be [rows >= trace_row0 + traced steps, trace_chains, trace_temps, dim]")
-        a.trace_every = te
-        a.trace_chains = trace.shape[1]
-        a.trace_temps = trace.shape[2]
-    a.trace_row0 = trace_row0
-    if accept_flags is not None and tuple(accept_flags.shape) != (n_steps, Cn, T):
-        raise ValueError("accept_flags must be [n_steps, n_chains, n_temps]")
-    a.accept_flags = _opt(accept_flags, "accept_flags", torch.uint8)
-    tdesc = target.desc()
-    pdesc = proposal.desc()
-    rc = lib.ptrwm_run(C.byref(tdesc), C.byref(pdesc), C.byref(a), _stream(state.device))
-    if rc != 0:
-        raise PTRWMError(rc, "ptrwm_run")
+    """One-shot form: enqueue ``n_steps`` fused MH(+swap) steps for every (chain, temperature) replica.
+    ``per_launch``: ext_prop, ext_u, ext_swap_u, trace, trace_logp, trace_row0, trace_every, accept_flags."""
+    RunPlan(target, proposal, state=state, logp=logp, beta=beta, burn_in=burn_in, swap_every=swap_every,
+            swap_mode=swap_mode, swap_order=swap_order, seed=seed, chain_offset=chain_offset, n_accept=n_accept,
+            sq_jump=sq_jump, swap_accept=swap_accept, last_swap_ordinal=last_swap_ordinal).launch(
+        step0, n_steps, **per_launch)
