@@ -153,7 +153,8 @@ typedef struct ptrwm_run_args {
   int32_t swap_every;
   int32_t swap_mode;
   int32_t swap_order;
-  int32_t reserved0;
+  int32_t swap_event_offset; /* swap events performed outside ptrwm_run (ptrwm_swap_sweep) before this call: added to
+                                the event numbers this call derives from step0 (attempt ordinals, even/odd parity) */
   uint64_t seed; /* Philox4x32-10 key */
   /* external randoms (test / fixture mode); all NULL => in-kernel Philox */
   const float *ext_prop;   /* [n_steps, n_chains, n_temps, ptrwm_ext_raw_per_step()] */
@@ -173,6 +174,18 @@ typedef struct ptrwm_run_args {
  * swaps) in one fused kernel launch on `stream`. */
 int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *proposal,
                   const ptrwm_run_args *args, void *stream);
+
+/* One stand-alone swap event over the current states: what the reference's
+ * ParallelTemperingRWM_GPU_Optimized._attempt_all_swaps() does when called on its own
+ * (pt_rwm_gpu_optimized.py:594-633; tests/debug_pt_performance.py:156).  Exactly the swap part of a ptrwm_run step:
+ * same decision rule, modes and orders.  Reads from `args`: n_temps, n_chains, chain_offset, state, logp, beta,
+ * swap_accept, last_swap_ordinal (both may be NULL), swap_mode, swap_order, seed, ext_swap_u (device
+ * [n_chains, n_temps-1] or NULL), and step0 = the Philox step index the swap uniforms are drawn at.
+ * `event_index` = 0-based number of this event in the run (attempt ordinals, even/odd parity); `rng_stream` in
+ * 1..15 selects the Philox stream (1 = the stream ptrwm_run's own swap events use, so a sweep with step0 = s,
+ * rng_stream = 1 reproduces the swap ptrwm_run would perform at step s).  sq_jump is not touched. */
+int32_t ptrwm_swap_sweep(const ptrwm_run_args *args, int32_t dim, int64_t event_index, int32_t rng_stream,
+                         void *stream);
 
 /* out[i] = log_density(x[i, :]) for i < n; x is device [n, dim], out device [n]. */
 int32_t ptrwm_logdensity(const ptrwm_target_desc *target, const float *x, float *out, int64_t n,

@@ -39,7 +39,7 @@ class RunArgs(C.Structure):
         ("state", C.c_void_p), ("logp", C.c_void_p), ("beta", C.c_void_p), ("n_accept", C.c_void_p),
         ("sq_jump", C.c_void_p), ("swap_accept", C.c_void_p), ("last_swap_ordinal", C.c_void_p),
         ("step0", C.c_int64), ("n_steps", C.c_int64), ("burn_in", C.c_int64), ("swap_every", C.c_int32),
-        ("swap_mode", C.c_int32), ("swap_order", C.c_int32), ("reserved0", C.c_int32), ("seed", C.c_uint64),
+        ("swap_mode", C.c_int32), ("swap_order", C.c_int32), ("swap_event_offset", C.c_int32), ("seed", C.c_uint64),
         ("ext_prop", C.c_void_p), ("ext_u", C.c_void_p), ("ext_swap_u", C.c_void_p), ("trace", C.c_void_p),
         ("trace_logp", C.c_void_p), ("trace_chains", C.c_int64), ("trace_temps", C.c_int32),
         ("trace_every", C.c_int32), ("trace_row0", C.c_int64), ("accept_flags", C.c_void_p),
@@ -63,6 +63,8 @@ def lib():
             getattr(_lib, f"oracle_logdensity_{sfx}").restype = C.c_int32
             getattr(_lib, f"oracle_propose_{sfx}").restype = C.c_int32
             getattr(_lib, f"oracle_run_{sfx}").restype = C.c_int32
+            sweep = getattr(_lib, f"oracle_swap_sweep_{sfx}")
+            sweep.restype, sweep.argtypes = C.c_int32, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32]
     return _lib
 
 
@@ -142,7 +144,7 @@ def propose(proposal: Proposal, dim, n, seed=0, ext_raw=None, precision="f32"):
 
 def run(target: Target, proposal: Proposal, *, state, logp, beta, step0, n_steps, burn_in=0, swap_every=1,
         swap_mode=SWAP_EXCHANGE, swap_order=ORDER_SEQUENTIAL, seed=0, chain_offset=0, ext_prop=None, ext_u=None,
-        ext_swap_u=None, trace_chains=0, trace_temps=0, want_flags=False, precision="f32"):
+        ext_swap_u=None, trace_chains=0, trace_temps=0, want_flags=False, precision="f32", swap_event_offset=0):
     """Runs the oracle.  Returns a dict with the updated state/logp (float32 copies) and statistics."""
     state = np.array(state, dtype=np.float32, order="C", copy=True)
     Cn, T, D = state.shape
@@ -162,6 +164,7 @@ def run(target: Target, proposal: Proposal, *, state, logp, beta, step0, n_steps
         setattr(a, k, v.ctypes.data)
     a.step0, a.n_steps, a.burn_in = step0, n_steps, burn_in
     a.swap_every, a.swap_mode, a.swap_order, a.seed = swap_every, swap_mode, swap_order, seed
+    a.swap_event_offset = swap_event_offset
     ext_prop, ext_u, ext_swap_u = _f32(ext_prop), _f32(ext_u), _f32(ext_swap_u)
     a.ext_prop, a.ext_u, a.ext_swap_u = _ptr(ext_prop), _ptr(ext_u), _ptr(ext_swap_u)
     if trace_chains:
@@ -174,6 +177,29 @@ def run(target: Target, proposal: Proposal, *, state, logp, beta, step0, n_steps
         a.accept_flags = res["accept_flags"].ctypes.data
     td, pd = target.desc(), proposal.desc()
     rc = getattr(lib(), f"oracle_run_{precision}")(C.byref(td), C.byref(pd), C.byref(a))
+    assert rc == 0, rc
+    res["state"], res["logp"] = state, logp
+    return res
+
+
+def swap_sweep(*, state, logp, beta, event_index, rng_step=0, rng_stream=2, swap_mode=SWAP_EXCHANGE,
+               swap_order=ORDER_SEQUENTIAL, seed=0, chain_offset=0, ext_swap_u=None, precision="f32"):
+    """One stand-alone swap event (oracle_swap_sweep: the reference's _attempt_all_swaps, pt_rwm_gpu_optimized.py:
+    594-633).  Returns the updated state / logp and the swap statistics of this one event."""
+    state = np.array(state, dtype=np.float32, order="C", copy=True)
+    Cn, T, D = state.shape
+    logp = np.array(logp, dtype=np.float32, order="C", copy=True).reshape(Cn, T)
+    beta = _f32(beta)
+    res = {"swap_accept": np.zeros((Cn, T), dtype=np.int64), "last_swap_ordinal": np.zeros((Cn, T), dtype=np.int64)}
+    a = RunArgs()
+    a.struct_size = C.sizeof(RunArgs)
+    a.n_temps, a.n_chains, a.chain_offset = T, Cn, chain_offset
+    a.state, a.logp, a.beta = state.ctypes.data, logp.ctypes.data, beta.ctypes.data
+    a.swap_accept, a.last_swap_ordinal = res["swap_accept"].ctypes.data, res["last_swap_ordinal"].ctypes.data
+    a.step0, a.swap_mode, a.swap_order, a.seed = rng_step, swap_mode, swap_order, seed
+    ext_swap_u = _f32(ext_swap_u)
+    a.ext_swap_u = _ptr(ext_swap_u)
+    rc = getattr(lib(), f"oracle_swap_sweep_{precision}")(C.byref(a), D, event_index, rng_stream)
     assert rc == 0, rc
     res["state"], res["logp"] = state, logp
     return res

@@ -67,6 +67,7 @@ class EngineRun:
         self.seed = draw_seed() if seed is None else int(seed)
         self.chain_offset = int(chain_offset)
         self.steps_done = 0
+        self.manual_sweeps = 0  # stand-alone swap events (swap_sweep) performed so far
         self.beta = torch.tensor(list(beta_ladder), device=device, dtype=torch.float32)
         x0 = torch.as_tensor(np.asarray(initial_state), dtype=torch.float32).to(device)
         # every temperature (and replica) starts from the same point (pt_rwm_gpu_optimized.py:478-484)
@@ -96,11 +97,20 @@ class EngineRun:
         if n_steps <= 0:
             return
         if trace is None and trace_logp is None:
-            self._plan.launch(self.steps_done, n_steps)
+            self._plan.launch(self.steps_done, n_steps, swap_event_offset=self.manual_sweeps)
         else:
             self._plan.launch(self.steps_done, n_steps, trace=trace, trace_logp=trace_logp, trace_row0=trace_row0,
-                              trace_every=trace_every)
+                              trace_every=trace_every, swap_event_offset=self.manual_sweeps)
         self.steps_done += n_steps
+
+    def swap_sweep(self) -> None:
+        """One stand-alone swap event over the current states (`_attempt_all_swaps()` called on its own,
+        pt_rwm_gpu_optimized.py:594-633; no host synchronisation).  Its uniforms come from Philox stream 2 at
+        counter = number of stand-alone sweeps so far, so they never coincide with the fused kernel's."""
+        if self.n_temps < 2:
+            return
+        self._plan.swap_sweep(rng_step=self.manual_sweeps, event_index=self.swap_events(), rng_stream=2)
+        self.manual_sweeps += 1
 
     # ---- summaries (each read synchronises) ---------------------------------------------------
     @property
@@ -109,7 +119,7 @@ class EngineRun:
 
     def swap_events(self) -> int:
         e = self.steps_done // self.swap_every - self.burn_in // self.swap_every
-        return max(0, e) if self.n_temps > 1 else 0
+        return max(0, e) + self.manual_sweeps if self.n_temps > 1 else 0
 
     def swap_attempts_per_replica(self) -> int:
         """Swap attempts one ladder has made so far (deterministic, needs no device read)."""

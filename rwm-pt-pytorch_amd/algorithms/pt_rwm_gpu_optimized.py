@@ -362,6 +362,14 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
     def _compute_log_densities_for_proposals(self, proposals):
         return self.target_dist.log_density(proposals)
 
+    def _attempt_all_swaps(self):
+        """One swap sweep over the current states, outside the step schedule (reference :594-633; called on its own
+        by tests/debug_pt_performance.py:156).  Counted in num_swap_attempts / num_swap_acceptances; the stored
+        chain is not extended (the reference appends states in step(), not here)."""
+        self._ensure_started()
+        self._run.swap_sweep()
+        self._chain_cache = None
+
     def get_diagnostic_info(self):
         return {
             "device": str(self.device),

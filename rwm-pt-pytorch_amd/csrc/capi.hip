@@ -118,6 +118,79 @@ __global__ void philox_raw_kernel(uint32_t *__restrict__ out, long long n, uint3
   out[4 * i + 3] = r.w;
 }
 
+// Stand-alone swap event: one workgroup per ladder, thread t = temperature t.  The decision is swap_decide(), the
+// code the fused kernel runs; the row permutation goes through LDS in column chunks (a permutation of rows can be
+// applied to every block of columns independently), so any (n_temps, dim) fits the 32 KB static buffer.
+struct SweepArgs {
+  float *state, *logp;
+  const float *beta, *ext_swap_u;
+  long long *swap_accept, *last_swap_ordinal;
+  long long chain_offset, event_index;
+  unsigned long long step;
+  int n_temps, dim, swap_mode, swap_order, rng_stream, chunk;
+  unsigned k0, k1;
+};
+constexpr int kSweepLdsFloats = 8192;
+
+__global__ void __launch_bounds__(256) swap_sweep_kernel(const SweepArgs a) {
+  __shared__ float s_rows[kSweepLdsFloats];
+  __shared__ float s_l[256], s_u[256];
+  __shared__ int s_src[256];
+  const int T = a.n_temps, D = a.dim, tid = threadIdx.x, nthr = blockDim.x;
+  const long long chain = blockIdx.x;
+  const bool live = tid < T;
+  const int t = live ? tid : 0;
+  float my_l = a.logp[chain * T + t];
+  float us;
+  if (a.ext_swap_u != nullptr) {
+    us = (t < T - 1) ? a.ext_swap_u[chain * (T - 1) + t] : 2.0f;
+  } else {
+    // the counter layout of the fused kernel's swap stream (kernel.h): block 0 | step_hi, step, chain, t | stream | chain_hi
+    const unsigned long long gchain = (unsigned long long)(a.chain_offset + chain);
+    const u32x4 r = philox4x32_10((uint32_t)(a.step >> 32) << 16, (uint32_t)a.step, (uint32_t)gchain,
+                                  (uint32_t)t | ((uint32_t)a.rng_stream << 8) | ((uint32_t)(gchain >> 32) << 12), a.k0,
+                                  a.k1);
+    us = u01(r.x);
+  }
+  if (live) {
+    s_l[tid] = my_l;
+    s_u[tid] = us;
+  }
+  __syncthreads();
+  int src = t;
+  bool pair_acc = false;
+  swap_decide(T, t, 0, t, a.swap_mode, a.swap_order, (int)(a.event_index & 1), a.beta, a.beta[t], us, s_l, s_u, my_l, src,
+              pair_acc);
+  if (live) s_src[tid] = src;
+  __syncthreads();
+  float *gs = a.state + chain * T * (long long)D;
+  for (int c0 = 0; c0 < D; c0 += a.chunk) {
+    const int w = (D - c0 < a.chunk) ? D - c0 : a.chunk;
+    for (int i = tid; i < T * w; i += nthr) {
+      const int tt = i / w, dd = i - tt * w;
+      s_rows[i] = gs[tt * D + c0 + dd];
+    }
+    __syncthreads();
+    for (int i = tid; i < T * w; i += nthr) {
+      const int tt = i / w, dd = i - tt * w;
+      gs[tt * D + c0 + dd] = s_rows[s_src[tt] * w + dd];
+    }
+    __syncthreads();
+  }
+  if (live) {
+    const long long rep = chain * T + t;
+    a.logp[rep] = my_l;
+    if (pair_acc) {
+      if (a.swap_accept != nullptr) a.swap_accept[rep] += 1;
+      if (a.last_swap_ordinal != nullptr) {
+        const long long ord =
+            (a.swap_order == PTRWM_ORDER_SEQUENTIAL) ? a.event_index * (T - 1) + t + 1 : a.event_index + 1;
+        if (ord > a.last_swap_ordinal[rep]) a.last_swap_ordinal[rep] = ord;
+      }
+    }
+  }
+}
+
 template <template <int> class Proposal>
 static hipError_t launch_propose(int wi, float *out, long long n, int D, int T, const float *ts, const PParams &pp,
                                  const float *ext_raw, int n_raw, unsigned k0, unsigned k1, hipStream_t st) {
@@ -265,7 +338,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
     k.n_steps = (int)n;
     const long long burn_left = args->burn_in - step0;
     k.burn_left = burn_left <= 0 ? 0 : (burn_left > n ? (int)n : (int)burn_left);
-    k.first_swap_event = ev0;
+    k.first_swap_event = ev0 + args->swap_event_offset;
     k.steps_to_swap = (int)(se - step0 % se);
     k.full.ext_prop = ext ? args->ext_prop + done * reps * raw : nullptr;
     k.full.ext_u = ext ? args->ext_u + done * reps : nullptr;
@@ -281,6 +354,42 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
     done += n;
   }
   return PTRWM_OK;
+}
+
+int32_t ptrwm_swap_sweep(const ptrwm_run_args *args, int32_t dim, int64_t event_index, int32_t rng_stream,
+                         void *stream) {
+  if (args == nullptr) return PTRWM_E_NULL;
+  if (args->struct_size != sizeof(ptrwm_run_args)) return PTRWM_E_STRUCT;
+  if (dim < 1 || dim > PTRWM_MAX_DIM) return PTRWM_E_DIM;
+  if (args->n_temps < 1 || args->n_temps > PTRWM_MAX_TEMPS) return PTRWM_E_TEMPS;
+  if (args->n_chains < 0 || args->n_chains > 0x7fffffffll || args->step0 < 0 || event_index < 0 || rng_stream < 1 ||
+      rng_stream > 15)
+    return PTRWM_E_ARG;
+  if (args->swap_mode != PTRWM_SWAP_EXCHANGE && args->swap_mode != PTRWM_SWAP_REFERENCE_COPY) return PTRWM_E_ARG;
+  if (args->swap_order != PTRWM_ORDER_SEQUENTIAL && args->swap_order != PTRWM_ORDER_EVEN_ODD) return PTRWM_E_ARG;
+  if (args->n_chains == 0 || args->n_temps == 1) return PTRWM_OK;  // nothing to exchange
+  if (args->state == nullptr || args->logp == nullptr || args->beta == nullptr) return PTRWM_E_NULL;
+  SweepArgs a;
+  a.state = args->state;
+  a.logp = args->logp;
+  a.beta = args->beta;
+  a.ext_swap_u = args->ext_swap_u;
+  a.swap_accept = (long long *)args->swap_accept;
+  a.last_swap_ordinal = (long long *)args->last_swap_ordinal;
+  a.chain_offset = args->chain_offset;
+  a.event_index = event_index;
+  a.step = (unsigned long long)args->step0;
+  a.n_temps = args->n_temps;
+  a.dim = dim;
+  a.swap_mode = args->swap_mode;
+  a.swap_order = args->swap_order;
+  a.rng_stream = rng_stream;
+  a.chunk = kSweepLdsFloats / args->n_temps;  // >= 32 columns per pass
+  a.k0 = (unsigned)(args->seed & 0xffffffffull);
+  a.k1 = (unsigned)(args->seed >> 32);
+  const unsigned block = (unsigned)((args->n_temps + 63) / 64 * 64);
+  hipLaunchKernelGGL(swap_sweep_kernel, dim3((unsigned)args->n_chains), dim3(block), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? PTRWM_OK : PTRWM_E_LAUNCH;
 }
 
 int32_t ptrwm_logdensity(const ptrwm_target_desc *target, const float *x, float *out, int64_t n, void *stream) {

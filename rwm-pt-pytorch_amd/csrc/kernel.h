@@ -73,11 +73,78 @@ __device__ __forceinline__ bool swap_accept_test(float u, float log_prob) {
   return (log_prob >= 0.0f) ? (u < 1.0f) : (u < hw_exp(log_prob));
 }
 
-// DP    compile-time width of the per-thread register arrays (>= dim)
-// EXACT dim == DP is known at compile time: every per-dimension predicate folds away.  Otherwise
-//       dim is a wave-uniform run-time value, re-read (opaquely) every step so the compiler tests
-//       `d < dim` with one scalar compare in place instead of hoisting DP booleans into SGPRs.
-// FULL  fixture/trace variant: external randoms, per-step trace and accept-flag outputs.
+// The decision part of one swap event (pt_rwm_gpu_optimized.py:594-633), shared by the fused step kernel and the
+// stand-alone sweep kernel (capi.hip).  In: this thread's temperature t (0 for idle threads), base = slot of
+// temperature 0 of its ladder, slot = base + t, us = its swap uniform, my_l = its log-density; s_l / s_u = the
+// ladder's published log-densities and uniforms (already synchronised); par = parity of the event (even/odd order).
+// Out: my_l = the log-density that ends up at temperature t, src = the slot whose vector does, pair_acc = pair
+// (t, t+1) accepted (recorded on the thread of temperature t).
+__device__ __forceinline__ void swap_decide(int T, int t, int base, int slot, int swap_mode, int swap_order, int par,
+                                            const float *__restrict__ beta, float beta_t, float us, const float *s_l,
+                                            const float *s_u, float &my_l, int &src, bool &pair_acc) {
+  if (swap_order == PTRWM_ORDER_SEQUENTIAL) {
+    if (swap_mode == PTRWM_SWAP_EXCHANGE) {
+      // The sweep j = 0..T-2 carries one state upward: at pair j the state now at position j (carried) meets
+      // the still-untouched state of position j+1.  Every thread of the ladder replays the scan from the
+      // published original values (uniform addresses: LDS broadcasts, no dependent cross-lane traffic) and
+      // keeps what lands on its own position.
+      float car_l = s_l[base];
+      int car_i = base;
+      for (int j = 0; j < T - 1; ++j) {
+        const float lk = s_l[base + j + 1];
+        const float u = s_u[base + j];
+        const float bj = beta[j], bk = beta[j + 1];
+        const bool ok = swap_accept_test(u, swap_log_prob(bj, bk, car_l, lk));
+        const int ik = base + j + 1;
+        if (t == j) {
+          my_l = ok ? lk : car_l;
+          src = ok ? ik : car_i;
+          pair_acc = ok;
+        }
+        const float nl = ok ? car_l : lk;
+        const int ni = ok ? car_i : ik;
+        car_l = nl;
+        car_i = ni;
+      }
+      if (t == T - 1) {
+        my_l = car_l;
+        src = car_i;
+      }
+    } else {
+      // reference_copy: row j <- row k, row k untouched, so every pair compares the original rows j and j+1:
+      // no carried state, fully parallel.
+      if (t < T - 1) {
+        const float lk = s_l[slot + 1];
+        const bool ok = swap_accept_test(us, swap_log_prob(beta_t, beta[t + 1], my_l, lk));
+        if (ok) {
+          my_l = lk;
+          src = slot + 1;
+        }
+        pair_acc = ok;
+      }
+    }
+  } else {
+    // even/odd: event n attempts the disjoint pairs (j, j+1) with j == n (mod 2)
+    const bool lower = ((t & 1) == par);          // this thread is the lower index j of its pair
+    const int partner_t = lower ? t + 1 : t - 1;
+    const bool valid = partner_t >= 0 && partner_t < T;
+    if (valid) {
+      const int partner = base + partner_t;
+      const float l_other = s_l[partner];
+      const float u_low = lower ? us : s_u[partner];
+      const int tj = lower ? t : partner_t;
+      const float lj = lower ? my_l : l_other;
+      const float lk = lower ? l_other : my_l;
+      const bool ok = swap_accept_test(u_low, swap_log_prob(beta[tj], beta[tj + 1], lj, lk));
+      if (ok && (lower || swap_mode == PTRWM_SWAP_EXCHANGE)) {
+        my_l = l_other;
+        src = partner;
+      }
+      pair_acc = ok && lower;
+    }
+  }
+}
+
 // dst[i] = src[i] for i = tid, tid + nthr, ... < total with sixteen independent loads in flight per thread: full
 // chunks unpredicated, then one predicated chunk for the remainder.  (A plain loop waits for every load before
 // issuing the next one when the stride is a run-time value: 1.7x slower for the one-step-per-launch case.)
@@ -128,8 +195,16 @@ __device__ __forceinline__ int fresh_dim(int d0) {
 #ifndef PTRWM_WAVES_MID
 #define PTRWM_WAVES_MID 2
 #endif
-constexpr int min_waves_per_simd(int dp) { return dp <= 44 ? PTRWM_WAVES_SMALL : (dp <= 64 ? PTRWM_WAVES_MID : 1); }
+// Width 40: four workgroups would need 4 x (40 KB slab + 2 KB) of the CU's 160 KB LDS, so three is what fits.
+constexpr int min_waves_per_simd(int dp) {
+  return dp <= 36 ? PTRWM_WAVES_SMALL : (dp <= 44 ? 3 : (dp <= 64 ? PTRWM_WAVES_MID : 1));
+}
 
+// DP    compile-time width of the per-thread register arrays (>= dim)
+// EXACT dim == DP is known at compile time: every per-dimension predicate folds away.  Otherwise
+//       dim is a wave-uniform run-time value, re-read (opaquely) every step so the compiler tests
+//       `d < dim` with one scalar compare in place instead of hoisting DP booleans into SGPRs.
+// FULL  fixture/trace variant: external randoms, per-step trace and accept-flag outputs.
 template <class Target, class Proposal, int DP, bool EXACT, bool FULL>
 __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_step_kernel(const KArgs a) {
   const int lane = threadIdx.x & 63;
@@ -289,68 +364,8 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       s_l[slot] = my_l;
       s_u[slot] = us;
       sync_group();
-      if (a.swap_order == PTRWM_ORDER_SEQUENTIAL) {
-        if (a.swap_mode == PTRWM_SWAP_EXCHANGE) {
-          // The sweep j = 0..T-2 carries one state upward: at pair j the state now at position j (carried) meets
-          // the still-untouched state of position j+1.  Every thread of the ladder replays the scan from the
-          // published original values (uniform addresses: LDS broadcasts, no dependent cross-lane traffic) and
-          // keeps what lands on its own position.
-          float car_l = s_l[base];
-          int car_i = base;
-          for (int j = 0; j < T - 1; ++j) {
-            const float lk = s_l[base + j + 1];
-            const float u = s_u[base + j];
-            const float bj = a.beta[j], bk = a.beta[j + 1];
-            const bool ok = swap_accept_test(u, swap_log_prob(bj, bk, car_l, lk));
-            const int ik = base + j + 1;
-            if (t == j) {
-              my_l = ok ? lk : car_l;
-              src = ok ? ik : car_i;
-              pair_acc = ok;
-            }
-            const float nl = ok ? car_l : lk;
-            const int ni = ok ? car_i : ik;
-            car_l = nl;
-            car_i = ni;
-          }
-          if (t == T - 1) {
-            my_l = car_l;
-            src = car_i;
-          }
-        } else {
-          // reference_copy: row j <- row k, row k untouched, so every pair compares the original rows j and j+1:
-          // no carried state, fully parallel.
-          if (t < T - 1) {
-            const float lk = s_l[slot + 1];
-            const bool ok = swap_accept_test(us, swap_log_prob(beta_t, a.beta[t + 1], my_l, lk));
-            if (ok) {
-              my_l = lk;
-              src = slot + 1;
-            }
-            pair_acc = ok;
-          }
-        }
-      } else {
-        // even/odd: event n attempts the disjoint pairs (j, j+1) with j == n (mod 2)
-        const int par = (ev_par0 + swap_in_call) & 1;
-        const bool lower = ((t & 1) == par);          // this thread is the lower index j of its pair
-        const int partner_t = lower ? t + 1 : t - 1;
-        const bool valid = partner_t >= 0 && partner_t < T;
-        if (valid) {
-          const int partner = base + partner_t;
-          const float l_other = s_l[partner];
-          const float u_low = lower ? us : s_u[partner];
-          const int tj = lower ? t : partner_t;
-          const float lj = lower ? my_l : l_other;
-          const float lk = lower ? l_other : my_l;
-          const bool ok = swap_accept_test(u_low, swap_log_prob(a.beta[tj], a.beta[tj + 1], lj, lk));
-          if (ok && (lower || a.swap_mode == PTRWM_SWAP_EXCHANGE)) {
-            my_l = l_other;
-            src = partner;
-          }
-          pair_acc = ok && lower;
-        }
-      }
+      swap_decide(T, t, base, slot, a.swap_mode, a.swap_order, (ev_par0 + swap_in_call) & 1, a.beta, beta_t, us, s_l, s_u,
+                  my_l, src, pair_acc);
       if (pair_acc) {
         ++n_swap_acc;
         last_event = swap_in_call;

@@ -95,7 +95,7 @@ class RunArgs(C.Structure):
         ("swap_every", C.c_int32),
         ("swap_mode", C.c_int32),
         ("swap_order", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("swap_event_offset", C.c_int32),
         ("seed", C.c_uint64),
         ("ext_prop", C.c_void_p),
         ("ext_u", C.c_void_p),
@@ -117,6 +117,7 @@ SYMBOLS = {
     "ptrwm_ext_raw_per_step": (C.c_int32, [C.c_int32, C.c_int32]),
     "ptrwm_has_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "ptrwm_run": (C.c_int32, [C.POINTER(TargetDesc), C.POINTER(ProposalDesc), C.POINTER(RunArgs), C.c_void_p]),
+    "ptrwm_swap_sweep": (C.c_int32, [C.POINTER(RunArgs), C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "ptrwm_logdensity": (C.c_int32, [C.POINTER(TargetDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ptrwm_propose": (
         C.c_int32,
@@ -355,11 +356,13 @@ class RunPlan:
         trace_row0: int = 0,
         trace_every: int = 1,
         accept_flags: Optional[torch.Tensor] = None,  # [n_steps, C, T] uint8
+        swap_event_offset: int = 0,  # stand-alone sweeps (swap_sweep) performed before this launch
     ) -> None:
         """Enqueue ``n_steps`` fused MH(+swap) steps, starting at global step ``step0``, on the current stream."""
         a = self._a
         a.step0 = step0
         a.n_steps = n_steps
+        a.swap_event_offset = swap_event_offset
         plain = (ext_prop is None and ext_u is None and ext_swap_u is None and trace is None and trace_logp is None
                  and accept_flags is None)
         if not (plain and self._plain):
@@ -391,6 +394,22 @@ class RunPlan:
         rc = self._lib.ptrwm_run(self._refs[2], self._refs[3], self._refs[4], _stream(self.device))
         if rc != 0:
             raise PTRWMError(rc, "ptrwm_run")
+
+    def swap_sweep(self, rng_step: int, event_index: int, rng_stream: int = 2,
+                   ext_swap_u: Optional[torch.Tensor] = None) -> None:
+        """One stand-alone swap event over the current states (the reference's ``_attempt_all_swaps()`` called on
+        its own).  Swap uniforms: ``ext_swap_u`` [C, T-1], else Philox stream ``rng_stream`` at step ``rng_step``
+        (stream 1 = the stream the fused kernel's own swap events use)."""
+        a = self._a
+        Cn, T, D = self.shape
+        if ext_swap_u is not None and tuple(ext_swap_u.shape) != (Cn, T - 1):
+            raise ValueError(f"ext_swap_u must be [{Cn}, {T - 1}]")
+        a.step0 = rng_step
+        a.ext_swap_u = _opt(ext_swap_u, "ext_swap_u", torch.float32)
+        self._plain = False  # per-launch fields of _a were touched: the next launch() rewrites them
+        rc = self._lib.ptrwm_swap_sweep(self._refs[4], D, event_index, rng_stream, _stream(self.device))
+        if rc != 0:
+            raise PTRWMError(rc, "ptrwm_swap_sweep")
 
 
 def run(

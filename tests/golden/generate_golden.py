@@ -11,6 +11,7 @@ What is captured:
   proposals.npz    raw torch randoms and the increments `proposal.sample()` makes from them
   rwm_*.npz        full RandomWalkMH_GPU_Optimized trajectories + the random tensors they consumed
   pt_*.npz         full ParallelTemperingRWM_GPU_Optimized trajectories + their random tensors
+  pt_sweep.npz     `_attempt_all_swaps()` called on its own on a batch of ladders
   numpy_baseline.json / numpy_*.npz   the NumPy CPU samplers (algorithms/rwm.py, pt_rwm.py)
 """
 import contextlib
@@ -300,6 +301,42 @@ def gen_pt(T):
         save(name + ".npz", **arrays)
 
 
+def gen_sweep(T):
+    """`_attempt_all_swaps()` called on its own (pt_rwm_gpu_optimized.py:594-633, as tests/debug_pt_performance.py:156
+    does): a batch of independent ladders, each given random states, the matching log-densities and its own swap
+    uniforms; the reference's states / log-densities / counters after ONE sweep are recorded."""
+    print("stand-alone swap sweep fixture")
+    t = T["rc15_d30"]
+    D = t.dim
+    ladder = [float(0.01 ** (i / 11)) for i in range(12)]
+    Tn, n_lad = len(ladder), 48
+    rng = np.random.default_rng(777)
+    st0 = rng.normal(0.0, 6.0, size=(n_lad, Tn, D)).astype(np.float32)
+    us = rng.random(size=(n_lad, Tn - 1)).astype(np.float32)
+    out_state, out_logp, in_logp, acc, att, rate, esjd = [], [], [], [], [], [], []
+    for c in range(n_lad):
+        np.random.seed(5)
+        alg = quiet(ref_alg.ParallelTemperingRWM_GPU_Optimized, D, 2.38**2 / D, t, True, beta_ladder=ladder,
+                    swap_every=10, burn_in=0, device="cpu", pre_allocate_steps=4)
+        alg.current_states = torch.from_numpy(st0[c].copy())
+        alg.current_log_densities = t.log_density(alg.current_states).to(torch.float32)
+        in_logp.append(alg.current_log_densities.numpy().copy())
+        alg.precomputed_swap_randoms = torch.from_numpy(us[c].copy())
+        alg.swap_random_index = 0
+        alg._attempt_all_swaps()
+        out_state.append(alg.current_states.numpy().copy())
+        out_logp.append(alg.current_log_densities.numpy().copy())
+        acc.append(alg.num_swap_acceptances)
+        att.append(alg.num_swap_attempts)
+        rate.append(alg.swap_acceptance_rate)
+        esjd.append(alg.pt_esjd)
+    save("pt_sweep.npz", state_in=st0, logp_in=np.asarray(in_logp, np.float32), swap_u=us,
+         beta_ladder=np.asarray(ladder, np.float64), state_out=np.asarray(out_state, np.float32),
+         logp_out=np.asarray(out_logp, np.float32), num_swap_acceptances=np.asarray(acc, np.int64),
+         num_swap_attempts=np.asarray(att, np.int64), swap_acceptance_rate=np.asarray(rate, np.float64),
+         pt_esjd=np.asarray(esjd, np.float64), target_key=np.array("rc15_d30"))
+
+
 # ------------------------------------------------------------------------------------------------
 # NumPy CPU samplers (BASELINE config 1 and a small PT run)
 # ------------------------------------------------------------------------------------------------
@@ -356,7 +393,7 @@ def gen_numpy():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["logdensity", "proposals", "rwm", "pt", "numpy"]
+    which = sys.argv[1:] or ["logdensity", "proposals", "rwm", "pt", "sweep", "numpy"]
     T = make_targets()
     if "logdensity" in which:
         gen_logdensity(T)
@@ -366,5 +403,7 @@ if __name__ == "__main__":
         gen_rwm(T)
     if "pt" in which:
         gen_pt(T)
+    if "sweep" in which:
+        gen_sweep(T)
     if "numpy" in which:
         gen_numpy()

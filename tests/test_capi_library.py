@@ -111,6 +111,19 @@ def test_validation_needs_no_gpu(engine):
     assert lib.ptrwm_logdensity(C.byref(td), None, None, 1, None) == -2
     td.dim = 11
     assert lib.ptrwm_logdensity(C.byref(td), None, None, 0, None) == 0  # empty batch: ok, nothing launched
+    # stand-alone swap sweep: same argument block, same error codes
+    sa = engine.RunArgs()
+    assert lib.ptrwm_swap_sweep(None, 30, 0, 1, None) == -1
+    assert lib.ptrwm_swap_sweep(C.byref(sa), 30, 0, 1, None) == -6
+    sa.struct_size, sa.n_temps, sa.n_chains = C.sizeof(engine.RunArgs), 8, 4
+    assert lib.ptrwm_swap_sweep(C.byref(sa), 105, 0, 1, None) == -2
+    assert lib.ptrwm_swap_sweep(C.byref(sa), 30, 0, 0, None) == -5 and lib.ptrwm_swap_sweep(C.byref(sa), 30, 0, 16, None) == -5
+    assert lib.ptrwm_swap_sweep(C.byref(sa), 30, -1, 1, None) == -5
+    assert lib.ptrwm_swap_sweep(C.byref(sa), 30, 0, 1, None) == -1  # state pointers missing
+    sa.n_temps = 1
+    assert lib.ptrwm_swap_sweep(C.byref(sa), 30, 0, 1, None) == 0  # one temperature: nothing to exchange
+    sa.n_temps = 257
+    assert lib.ptrwm_swap_sweep(C.byref(sa), 30, 0, 1, None) == -3
 
 
 def test_product_refuses_to_run_without_its_library_or_a_gpu(engine, tmp_path):
@@ -121,6 +134,17 @@ def test_product_refuses_to_run_without_its_library_or_a_gpu(engine, tmp_path):
     t = engine.Target(engine.TARGET_ROUGH_CARPET, 3, p=(-1, 0, 1, -1, -1, -1, 0))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         engine.logdensity(t, torch.zeros(2, 3))
+    # the run plan validates once, on construction: CPU tensors, wrong shapes and wrong dtypes never reach a launch
+    st, lp, b = torch.zeros(2, 4, 3), torch.zeros(2, 4), torch.ones(4)
+    prop = engine.Proposal(engine.PROPOSAL_NORMAL, torch.ones(4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        engine.RunPlan(t, prop, state=st, logp=lp, beta=b)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        engine.run(t, prop, state=st, logp=lp, beta=b, step0=0, n_steps=1)
+    with pytest.raises(ValueError, match="state dim"):
+        engine.RunPlan(t, prop, state=torch.zeros(2, 4, 5), logp=lp, beta=b)
+    with pytest.raises(ValueError, match="shapes do not match"):
+        engine.RunPlan(t, prop, state=st, logp=torch.zeros(2, 3), beta=b)
     # nothing in the product package imports the oracle
     pkg = os.path.join(ROOT, "rwm-pt-pytorch_amd")
     for dirpath, _, files in os.walk(pkg):

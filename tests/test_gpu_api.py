@@ -376,3 +376,35 @@ def test_esjd_is_maximised_near_acceptance_0234(device):
     xs = torch.linspace(-8, 8, 33, device=device)
     want = sum(w * torch.exp(-0.5 * (xs - m) ** 2) / np.sqrt(2 * np.pi) for w, m in zip([0.5, 0.3, 0.2], [-5.0, 0.0, 5.0]))
     assert torch.allclose(rc.density_1d(xs), want, rtol=1e-5, atol=1e-7)
+
+
+def test_attempt_all_swaps_standalone(device):
+    """`_attempt_all_swaps()` on its own (tests/debug_pt_performance.py:156 in the reference): one sweep over the
+    current states, counted in the swap statistics, states stay a permutation of the ladder's rows (exchange mode)."""
+    torch.manual_seed(3)
+    target = RoughCarpetDistributionTorch(30, device=device, mode_centers=[-15.0, 0.0, 15.0])
+    alg = ParallelTemperingRWM_GPU_Optimized(30, 2.38**2 / 30, target, geom_temp_spacing=True, swap_every=1000,
+                                             device=device, num_replicas=64, seed=11)
+    T = len(alg.beta_ladder)
+    for _ in range(30):
+        alg.step()
+    assert alg.num_swap_attempts == 0
+    before = alg._run.state.clone()
+    lp_before = alg._run.logp.clone()
+    alg._attempt_all_swaps()
+    alg._attempt_all_swaps()
+    assert alg.num_swap_attempts == 2 * (T - 1) * 64
+    assert 0 < alg.num_swap_acceptances <= alg.num_swap_attempts
+    after, lp_after = alg._run.state, alg._run.logp
+    assert torch.equal(lp_after.sort(dim=1).values, lp_before.sort(dim=1).values)
+    assert torch.equal(after.sum(dim=1), before.sum(dim=1)) or torch.allclose(after.sum(dim=1), before.sum(dim=1), atol=1e-4)
+    assert not torch.equal(after, before)
+    # the log-densities still belong to the states they travel with
+    from ptrwm_hip import logdensity
+    chk = logdensity(alg._run.target, after.view(-1, 30)).view_as(lp_after)
+    assert torch.allclose(chk, lp_after, rtol=1e-5, atol=1e-4)
+    # stepping resumes normally afterwards (event numbering includes the stand-alone sweeps)
+    alg2_attempts = alg.num_swap_attempts
+    for _ in range(5):
+        alg.step()
+    assert alg.num_swap_attempts == alg2_attempts

@@ -550,3 +550,80 @@ def test_zero_chains_and_support_edges(device):
     assert np.array_equal(np.isfinite(got["logp"]), inside)
     assert inside.mean() > 0.5
     assert (got["accept_flags"] == want["accept_flags"]).mean() > 0.995
+
+
+def gpu_sweep(device, *, state, logp, beta, event_index, dim, **kw):
+    """Mirror of oracle.swap_sweep for the engine (ptrwm_swap_sweep through a RunPlan)."""
+    Cn, T, D = state.shape
+    st, lp = dev_t(state, device), dev_t(logp, device).reshape(Cn, T).contiguous()
+    sw = torch.zeros(Cn, T, dtype=torch.int64, device=device)
+    lo = torch.zeros(Cn, T, dtype=torch.int64, device=device)
+    spec = H.target_spec("rc15_d30") if dim == 30 else None
+    tgt = spec.engine(device) if spec is not None else E.Target(E.TARGET_HYPERCUBE, dim, p=(0.0, 1.0))
+    prop = E.Proposal(E.PROPOSAL_NORMAL, torch.ones(T, device=device))
+    ext = kw.pop("ext_swap_u", None)
+    plan = E.RunPlan(tgt, prop, state=st, logp=lp, beta=dev_t(beta, device), swap_accept=sw, last_swap_ordinal=lo,
+                     swap_mode=kw.pop("swap_mode", E.SWAP_EXCHANGE), swap_order=kw.pop("swap_order", E.ORDER_SEQUENTIAL),
+                     seed=kw.pop("seed", 0), chain_offset=kw.pop("chain_offset", 0))
+    plan.swap_sweep(kw.pop("rng_step", 0), event_index, kw.pop("rng_stream", 2),
+                    ext_swap_u=None if ext is None else dev_t(ext, device))
+    assert not kw
+    torch.cuda.synchronize()
+    return {"state": st.cpu().numpy(), "logp": lp.cpu().numpy(), "swap_accept": sw.cpu().numpy(),
+            "last_swap_ordinal": lo.cpu().numpy()}
+
+
+def test_standalone_swap_sweep_matches_reference(device):
+    """ptrwm_swap_sweep against the reference's own `_attempt_all_swaps()` outputs (tests/golden/pt_sweep.npz)."""
+    f = H.load("pt_sweep.npz")
+    beta = f["beta_ladder"].astype(np.float32)
+    got = gpu_sweep(device, state=f["state_in"], logp=f["logp_in"], beta=beta, event_index=0, dim=30,
+                    swap_mode=E.SWAP_REFERENCE_COPY, ext_swap_u=f["swap_u"])
+    assert np.array_equal(got["state"], f["state_out"])
+    assert np.array_equal(got["logp"], f["logp_out"])
+    assert np.array_equal(got["swap_accept"].sum(1), f["num_swap_acceptances"])
+
+
+@pytest.mark.parametrize("T,D,Cn", [(2, 3, 70), (5, 30, 33), (12, 30, 20), (64, 7, 5), (100, 30, 4), (256, 104, 3),
+                                     (200, 33, 2)])
+def test_standalone_swap_sweep_vs_oracle(device, T, D, Cn):
+    """All four mode / order combinations, Philox uniforms (stream 2) and external ones, ladders up to 256
+    temperatures, dims up to 104 (several column chunks through the 32 KB exchange buffer): bit-exact."""
+    rng = np.random.default_rng(T * 131 + D)
+    st = rng.normal(0, 3, (Cn, T, D)).astype(np.float32)
+    lp = rng.normal(-50, 30, (Cn, T)).astype(np.float32)
+    lp[0, 0] = -np.inf  # a replica outside the support takes part in swaps like any other
+    beta = (0.01 ** (np.arange(T) / (T - 1))).astype(np.float32)
+    accepted = 0
+    for order in ("sequential", "even_odd"):
+        for mode in ("exchange", "reference_copy"):
+            for ev in (0, 7):
+                for ext in (None, rng.random((Cn, T - 1)).astype(np.float32)):
+                    kw = dict(state=st, logp=lp, beta=beta, event_index=ev, swap_mode=E.SWAP_MODES[mode],
+                              swap_order=E.SWAP_ORDERS[order], seed=99, chain_offset=3, rng_step=5, ext_swap_u=ext)
+                    want = O.swap_sweep(**kw)
+                    got = gpu_sweep(device, dim=D, **kw)
+                    for k in ("state", "logp", "swap_accept", "last_swap_ordinal"):
+                        assert np.array_equal(got[k], want[k]), (k, order, mode, ev, ext is None)
+                        accepted += int(want["swap_accept"].sum())
+    assert accepted > 0
+
+
+def test_standalone_sweep_equals_the_fused_kernels_swap(device):
+    """MH steps without a swap followed by ptrwm_swap_sweep on Philox stream 1 at the last step's index == the same
+    steps with the swap fused into the last one (same states, log-densities and swap counters)."""
+    spec = H.target_spec("rc15_d30")
+    T, Cn, N = 16, 40, 10
+    beta = (0.01 ** (np.arange(T) / (T - 1))).astype(np.float32)
+    prop = H.proposal_spec("Normal", 30, beta, base_variance_scalar=2.38**2 / 30)
+    st, lp = start_state(spec, Cn, T, np.random.default_rng(1))
+    for order in ("sequential", "even_odd"):
+        kw = dict(beta=beta, seed=31, chain_offset=2, swap_order=E.SWAP_ORDERS[order])
+        fused = gpu_run(spec, prop, device, state=st, logp=lp, step0=0, n_steps=N, swap_every=N, **kw)
+        plain = gpu_run(spec, prop, device, state=st, logp=lp, step0=0, n_steps=N, swap_every=10 * N, **kw)
+        assert plain["swap_accept"].sum() == 0 and fused["swap_accept"].sum() > 0
+        got = gpu_sweep(device, state=plain["state"], logp=plain["logp"], beta=beta, event_index=0, dim=30,
+                        rng_step=N - 1, rng_stream=1, **{k: v for k, v in kw.items() if k != "beta"})
+        assert np.array_equal(got["state"], fused["state"]) and np.array_equal(got["logp"], fused["logp"])
+        assert np.array_equal(got["swap_accept"], fused["swap_accept"])
+        assert np.array_equal(got["last_swap_ordinal"], fused["last_swap_ordinal"])

@@ -168,3 +168,27 @@ def test_pt_exchange_differs_from_reference_copy():
     assert not np.array_equal(a["state"], b["state"])
     # exchange conserves the multiset of rows at a swap; copy duplicates rows
     assert len({tuple(r) for r in a["state"][0]}) == T
+
+
+def test_standalone_swap_sweep_matches_reference():
+    """`_attempt_all_swaps()` called on its own (pt_rwm_gpu_optimized.py:594-633): the oracle's sweep reproduces the
+    reference's states, log-densities and counters on 48 random ladders, bit for bit (rows are only copied)."""
+    f = H.load("pt_sweep.npz")
+    beta = f["beta_ladder"].astype(np.float32)
+    T = len(beta)
+    for prec in ("f32", "f64"):
+        got = O.swap_sweep(state=f["state_in"], logp=f["logp_in"], beta=beta, event_index=0,
+                           swap_mode=O.SWAP_REFERENCE_COPY, swap_order=O.ORDER_SEQUENTIAL, ext_swap_u=f["swap_u"],
+                           precision=prec)
+        assert np.array_equal(got["state"], f["state_out"])
+        assert np.array_equal(got["logp"], f["logp_out"])
+        acc = got["swap_accept"].sum(1)
+        assert np.array_equal(acc, f["num_swap_acceptances"])
+        assert np.all(f["num_swap_attempts"] == T - 1)
+        # the reference refreshes its rate only when a swap is accepted (:627-633): acc / ordinal of the last accept
+        last = got["last_swap_ordinal"].max(1)
+        assert np.allclose(acc / np.maximum(last, 1), f["swap_acceptance_rate"], rtol=0, atol=1e-15)
+    # exchange mode differs from the reference's row copy exactly where a swap was accepted: it is a permutation
+    ex = O.swap_sweep(state=f["state_in"], logp=f["logp_in"], beta=beta, event_index=0, ext_swap_u=f["swap_u"])
+    assert np.array_equal(np.sort(ex["logp"], axis=1), np.sort(f["logp_in"], axis=1))
+    assert not np.array_equal(ex["state"], f["state_out"])
