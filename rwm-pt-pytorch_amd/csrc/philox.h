@@ -41,7 +41,7 @@ __device__ __forceinline__ void mul_hilo(uint32_t m, uint32_t x, uint32_t &hi, u
 
 // One Philox4x32-10 block.  The key schedule is wave-uniform (seed only), so the
 // ten round keys live in SGPRs; per round the VALU work is two 32x32->64
-// multiplies and two three-way xors.
+// multiplies (v_mad_u64_u32) and two three-way xors (v_bitop3_b32).
 __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -51,8 +51,18 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     // product into two SALU multiplies)
     mul_hilo(kPhiloxM0, c0, hi0, lo0);
     mul_hilo(kPhiloxM1, c2, hi1, lo1);
-    const uint32_t n0 = hi1 ^ c1 ^ k0;
-    const uint32_t n2 = hi0 ^ c3 ^ k1;
+    uint32_t n0, n2;
+    if (r >= 2) {
+      // one v_bitop3_b32 (0x96 = a ^ b ^ c) per three-way xor; hipcc does not form it by itself when one operand
+      // is an SGPR (the round key) and emits two v_xor_b32: 160 extra VALU instructions per dim-30 step
+      n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);
+      n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
+    } else {
+      // rounds 0 and 1 still see wave-uniform inputs in the step kernel (step, block index and their products):
+      // plain xors let the compiler fold those parts on the scalar unit
+      n0 = hi1 ^ c1 ^ k0;
+      n2 = hi0 ^ c3 ^ k1;
+    }
     c1 = lo1;
     c3 = lo0;
     c0 = n0;
