@@ -73,6 +73,18 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
   return u32x4{c0, c1, c2, c3};
 }
 
+// Parameter vectors (means, per-dimension scales) are read-only for the whole launch and indexed wave-uniformly.
+// Read through the constant address space they become scalar loads (s_load_dwordx*, SGPR operands) instead of
+// 64-lane vector loads of a single address.  (No kernel writes them, so the scalar cache cannot go stale.)
+// The pointer is passed through an empty asm once per evaluation so the loads stay inside the step loop: hoisted
+// out of it as loop invariants they would pin dozens of SGPRs for the whole launch (and spill).
+typedef const __attribute__((address_space(4))) float *const_float_ptr;
+__device__ __forceinline__ const_float_ptr uniform_vec(const float *p) {
+  uintptr_t v = (uintptr_t)p;
+  asm volatile("" : "+s"(v));
+  return (const_float_ptr)v;
+}
+
 // top 24 bits -> [0, 1): same lattice as torch.rand(float32)
 __device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * 0x1p-24f; }
 // top 24 bits -> (0, 1]

@@ -129,17 +129,23 @@ struct LaplaceProposal {
     const float au = __builtin_fabsf(u);
     const float arg = __builtin_fmaxf(-2.0f * au, -0.999999f);
     const float l1p = hw_log2(1.0f + arg) * kLn2;
-    const float sgn = (u > 0.0f) ? 1.0f : ((u < 0.0f) ? -1.0f : 0.0f);
-    return mul_rn(mul_rn(-scale, sgn), l1p);
+    // (-scale * sign(u)) * l1p: the product with sign(u) is exact, so this is scale*l1p with its sign flipped when
+    // u > 0 (and a zero when u == 0, where l1p == 0): one sign-bit operation instead of two compares, two selects
+    // and a multiply.  (~u has its sign bit set exactly when u >= +0.)
+    const float t = mul_rn(scale, l1p);
+    // v_bitop3_b32 truth table for a ^ (~b & c) with a = 0xf0, b = 0xcc, c = 0xaa: 0xf0 ^ (0x33 & 0xaa) = 0xd2
+    return __builtin_bit_cast(float, __builtin_amdgcn_bitop3_b32(__builtin_bit_cast(uint32_t, t),
+                                                                 __builtin_bit_cast(uint32_t, u), 0x80000000u, 0xd2));
   }
   __device__ __forceinline__ static float propose(float (&y)[DP], const float (&x)[DP], int D,
                                                   float tscale, const PParams &pp, const RngCtx &rc,
                                                   const float *ext_raw, float ext_u) {
     float u_acc = ext_u;
+    const const_float_ptr dsc = uniform_vec(pp.dim_scale);
     if (ext_raw != nullptr) {
 #pragma unroll
       for (int d = 0; d < DP; ++d)
-        if (d < D) y[d] = add_rn(x[d], transform(ext_raw[d], mul_rn(pp.dim_scale[d], tscale)));
+        if (d < D) y[d] = add_rn(x[d], transform(ext_raw[d], mul_rn(dsc[d], tscale)));
     } else {
       constexpr int NB = DP / 4 + 1;
 #pragma unroll
@@ -151,7 +157,7 @@ struct LaplaceProposal {
             const int d = 4 * c + q;
             if (d < DP && d < D) {
               const int ds = d < DP ? d : 0;
-              y[ds] = add_rn(x[ds], transform(u01(pick(r, q)), mul_rn(pp.dim_scale[ds], tscale)));
+              y[ds] = add_rn(x[ds], transform(u01(pick(r, q)), mul_rn(dsc[ds], tscale)));
             }
             if (d == D) u_acc = u01(pick(r, q));
           }

@@ -40,6 +40,7 @@ struct RoughCarpetT {
   template <bool SCALED, bool STRICT, bool TWO>
   __device__ __forceinline__ static float logp_impl(const float (&y)[DP], int D, const TParams &tp) {
     const float m0 = tp.p[0], m1 = tp.p[1], m2 = tp.p[2];
+    [[maybe_unused]] const const_float_ptr uv0 = SCALED ? uniform_vec(tp.vec0) : nullptr;
     // log2-domain log-weights
     const float w0 = tp.p[3] * kLog2e, w1 = tp.p[4] * kLog2e, w2 = tp.p[5] * kLog2e;
     const float nh = -0.5f * kLog2e;
@@ -48,7 +49,7 @@ struct RoughCarpetT {
     for (int d = 0; d < DP; ++d) {
       if (d < D) {
         float xs = y[d];
-        if constexpr (SCALED) xs *= tp.vec0[d];
+        if constexpr (SCALED) xs *= uv0[d];
         const float d0 = xs - m0, d1 = xs - m1, d2 = xs - m2;
         const float a0 = fmaf(d0 * d0, nh, w0);
         const float a1 = fmaf(d1 * d1, nh, w1);
@@ -95,14 +96,16 @@ struct ThreeMixture {
   template <bool SCALED>
   __device__ __forceinline__ static float logp_impl(const float (&y)[DP], int D, const TParams &tp) {
     float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
+    const const_float_ptr uv0 = uniform_vec(tp.vec0);
+    [[maybe_unused]] const const_float_ptr uv1 = SCALED ? uniform_vec(tp.vec1) : nullptr;
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
       if (d < D) {
         float xs = y[d];
-        if constexpr (SCALED) xs *= tp.vec1[d];
-        const float e0 = xs - tp.vec0[d];
-        const float e1 = xs - tp.vec0[D + d];
-        const float e2 = xs - tp.vec0[2 * D + d];
+        if constexpr (SCALED) xs *= uv1[d];
+        const float e0 = xs - uv0[d];
+        const float e1 = xs - uv0[D + d];
+        const float e2 = xs - uv0[2 * D + d];
         q0 = fmaf(e0, e0, q0);
         q1 = fmaf(e1, e1, q1);
         q2 = fmaf(e2, e2, q2);
@@ -132,11 +135,12 @@ struct FullRosenbrock {
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
     const float a = tp.p[0], b = tp.p[1];
     float s1 = 0.0f, s2 = 0.0f;
+    const const_float_ptr uv0 = uniform_vec(tp.vec0);
 #pragma unroll
     for (int i = 0; i + 1 < DP; ++i) {
       if (i + 1 < D) {
         const float r = y[i + 1] - y[i] * y[i];
-        const float c = y[i] - tp.vec0[i];
+        const float c = y[i] - uv0[i];
         s1 = fmaf(b * r, r, s1);
         s2 = fmaf(a * c, c, s2);
       }
@@ -155,10 +159,11 @@ struct EvenRosenbrock {
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
     const float a = tp.p[0], b = tp.p[1];
     float s1 = 0.0f, s2 = 0.0f;
+    const const_float_ptr uv0 = uniform_vec(tp.vec0);
 #pragma unroll
     for (int i = 0; 2 * i + 1 < DP; ++i) {
       if (2 * i + 1 < D) {
-        const float c = y[2 * i] - tp.vec0[i];
+        const float c = y[2 * i] - uv0[i];
         const float r = y[2 * i + 1] - y[2 * i] * y[2 * i];
         s1 = fmaf(a * c, c, s1);
         s2 = fmaf(b * r, r, s2);
@@ -251,15 +256,17 @@ struct DiagGaussian {
   template <bool SCALED_FORM>
   __device__ __forceinline__ static float quad(const float (&y)[DP], int D, const TParams &tp) {
     float q = 0.0f;
+    const const_float_ptr uv0 = uniform_vec(tp.vec0);
+    [[maybe_unused]] const const_float_ptr uv1 = SCALED_FORM ? nullptr : uniform_vec(tp.vec1);
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
       if (d < D) {
         if constexpr (SCALED_FORM) {
-          const float sx = tp.vec0[d] * y[d];
+          const float sx = uv0[d] * y[d];
           q = fmaf(sx, sx, q);
         } else {
-          const float c = y[d] - tp.vec0[d];
-          q = fmaf(c * tp.vec1[d], c, q);
+          const float c = y[d] - uv0[d];
+          q = fmaf(c * uv1[d], c, q);
         }
       }
       if ((d & 7) == 7) sched_fence_soft();
