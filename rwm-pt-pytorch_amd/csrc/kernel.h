@@ -7,11 +7,12 @@
 // with the replica's dim-vector, log-density and counters held in registers for
 // the whole launch: HBM is touched once to load and once to store the state.
 //
-// Thread map, T <= 64 ("narrow"): lane = cw * T + t (cw = chain slot within the wave, t = temperature),
-// chains_per_wave = 64 / T; lanes >= chains_per_wave*T idle (only when T does not divide 64); the four waves of
-// a workgroup are independent.  64 < T <= 256 ("wide"): one ladder per 256-thread workgroup, t = threadIdx.x.
+// Thread map.  T <= 64 ("narrow"): an exchange group is one wavefront, lane = cw * T + t (cw = chain slot within
+// the wave, t = temperature), chains_per_wave = 64 / T; lanes >= chains_per_wave*T idle (only when T does not divide
+// 64); a workgroup is four independent groups (measured 2 % faster than one-wave workgroups).  64 < T <= 256
+// ("wide"): one ladder per workgroup of ceil(T / 64) waves, t = threadIdx.x.
 // Either way a ladder lives inside one workgroup and swaps go through LDS (broadcast reads of the ladder's
-// log-densities, row exchange through the staging slab), never HBM.
+// log-densities, row exchange through the staging rows), never HBM.
 #pragma once
 #include "philox.h"
 #include "proposals.h"
@@ -24,6 +25,9 @@ namespace ptrwm {
 #endif
 constexpr int kBlockThreads = PTRWM_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
+// dynamic LDS bytes of a step-kernel workgroup of `threads` threads with register width dp: one row of dp floats
+// per thread plus its log-density and swap-uniform slots
+constexpr unsigned step_kernel_lds_bytes(int threads, int dp) { return (unsigned)(threads * (dp + 2)) * 4u; }
 
 // Arguments only the fixture / trace variant of the kernel (FULL = true) reads.  Keeping them out
 // of the production variant keeps its wave-uniform state inside the 100-odd SGPRs of a wave.
@@ -195,7 +199,7 @@ __device__ __forceinline__ int fresh_dim(int d0) {
 #ifndef PTRWM_WAVES_MID
 #define PTRWM_WAVES_MID 2
 #endif
-// Width 40: four workgroups would need 4 x (40 KB slab + 2 KB) of the CU's 160 KB LDS, so three is what fits.
+// (Width 40 at 4 waves/SIMD spilled ~75 VGPRs; 3 waves/SIMD = 168 VGPRs holds it.)
 constexpr int min_waves_per_simd(int dp) {
   return dp <= 36 ? PTRWM_WAVES_SMALL : (dp <= 44 ? 3 : (dp <= 64 ? PTRWM_WAVES_MID : 1));
 }
@@ -207,39 +211,32 @@ constexpr int min_waves_per_simd(int dp) {
 // FULL  fixture/trace variant: external randoms, per-step trace and accept-flag outputs.
 template <class Target, class Proposal, int DP, bool EXACT, bool FULL>
 __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_step_kernel(const KArgs a) {
-  const int lane = threadIdx.x & 63;
   const int T = a.n_temps;
   const int D0 = EXACT ? DP : a.dim;
   const int cpw = a.chains_per_wave;
-  const bool wide = T > 64;  // one ladder per workgroup instead of per wavefront (wave-uniform, grid-uniform)
-  long long chain0;
-  int cw_raw, t_raw;
-  if (wide) {
-    chain0 = blockIdx.x;
-    cw_raw = 0;
-    t_raw = threadIdx.x;
-  } else {
-    chain0 = ((long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * cpw;
-    if (chain0 >= a.n_chains) return;  // wave-uniform; narrow waves never meet at a workgroup barrier
-    cw_raw = lane / T;
-    t_raw = lane - cw_raw * T;
-  }
-  const bool live = wide ? (t_raw < T) : ((cw_raw < cpw) && (chain0 + cw_raw < a.n_chains));
+  // An exchange group is one wavefront holding cpw = 64 / T whole ladders (T <= 64, "narrow": a workgroup is four
+  // independent groups), or ceil(T / 64) wavefronts = the whole workgroup holding one ladder ("wide", cpw = 1).
+  // Thread tid of its group is (cw, t) with tid = cw * T + t either way.
+  const bool wide = T > 64;  // grid-uniform
+  const int tid = wide ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+  const long long chain0 = (wide ? (long long)blockIdx.x : (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * cpw;
+  if (chain0 >= a.n_chains) return;  // narrow only (wave-uniform; narrow waves never meet at a workgroup barrier)
+  const int cw_raw = tid / T;
+  const int t_raw = tid - cw_raw * T;
+  const bool live = (cw_raw < cpw) && (chain0 + cw_raw < a.n_chains);
   // idle threads shadow replica (chain0, 0): they compute but never store and are never an exchange source
   const int cw = live ? cw_raw : 0;
   const int t = live ? t_raw : 0;
   const long long chain = chain0 + cw;
-  const int rep_in_group = cw * T + t;  // replica index relative to (chain0, 0)
-  const long long rep = chain0 * T + rep_in_group;
+  const long long rep = chain0 * T + (live ? tid : 0);  // cw * T + t == tid for a live thread
 
-  // ---- LDS ------------------------------------------------------------------------------------------------
-  // s_stage: 256 rows of up to DP floats.  Narrow: each wave owns the slab [wave][64*DP] and packs its live
-  // replicas' rows back to back (row stride = dim).  Wide: the whole array is one slab, row = temperature.
-  // s_l / s_u: per-thread log-density and swap uniform, read back broadcast during a swap sweep.
-  __shared__ float s_stage[kWavesPerBlock][64 * DP];
-  __shared__ float s_l[kBlockThreads];
-  __shared__ float s_u[kBlockThreads];
-  // group-wide ordering of LDS accesses: the ladder's threads are one wave (narrow) or the workgroup (wide)
+  // ---- LDS (dynamic: group threads * (DP + 2) floats per group, sized by the launch: step_kernel_lds_bytes) --
+  // s_stage: one row of up to DP floats per thread; the group packs its live replicas' rows back to back (row
+  // stride = dim) for the coalesced state load / store and exchanges rows through it in a swap.
+  // s_l / s_u (behind the rows): per-thread log-density and swap uniform, read back broadcast during a swap sweep.
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  float *const s_stage = s_dyn + (wide ? 0 : (int)(threadIdx.x >> 6) * (64 * (DP + 2)));
+  // group-wide ordering of LDS accesses: the group is one wave (narrow) or the workgroup (wide)
   auto sync_group = [&]() {
     if (wide) {
       __syncthreads();
@@ -256,14 +253,13 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
   // read would touch 64 different cache lines per instruction.
   float x[DP], y[DP];
   {
-    const long long live_chains = wide ? 1 : ((a.n_chains - chain0 < cpw) ? (a.n_chains - chain0) : cpw);
+    const long long live_chains = (a.n_chains - chain0 < cpw) ? (a.n_chains - chain0) : cpw;
     const int stage_total = (int)live_chains * T * D0;  // floats of this group's run
     const float *__restrict__ gs = a.state + chain0 * T * (long long)D0;
-    float *const slab = wide ? &s_stage[0][0] : s_stage[threadIdx.x >> 6];
-    const int nthr = wide ? kBlockThreads : 64, tid = wide ? (int)threadIdx.x : lane;
-    stage_copy(slab, gs, stage_total, tid, nthr);
+    const int nthr = wide ? ((T + 63) & ~63) : 64;  // threads of the group = of the workgroup
+    stage_copy(s_stage, gs, stage_total, tid, nthr);
     sync_group();
-    const float *row = slab + (live ? tid : 0) * D0;  // idle threads shadow row 0 = replica (chain0, 0)
+    const float *row = s_stage + (live ? tid : 0) * D0;  // idle threads shadow row 0 = replica (chain0, 0)
 #pragma unroll
     for (int d = 0; d < DP; ++d) x[d] = (d < D0) ? row[d] : 0.0f;
   }
@@ -344,11 +340,14 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       // ---- temperature swaps on the post-MH log-densities (pt_rwm_gpu_optimized.py:594-633) ----
       // The exchange indices are rebuilt here from an opaque copy of threadIdx.x, so that none of them occupies a
       // register (or a scratch slot) across the MH part of the step.
-      const int slot = opaque_vgpr((int)threadIdx.x);           // this thread's slot in s_l / s_u
-      const int slab_slot0 = wide ? 0 : (slot & ~63);            // first slot of this thread's slab
-      const int row_in_slab = slot - slab_slot0;
-      const int base = live ? slot - t : slab_slot0;             // slot of temperature 0 of this thread's ladder
-      float *const slab = &s_stage[0][0] + (wide ? 0 : (slot >> 6) * (64 * DP));
+      const int tid_s = opaque_vgpr((int)threadIdx.x);
+      const int slot = wide ? tid_s : (tid_s & 63);  // this thread's slot in s_l / s_u and its row in s_stage
+      const int t = opaque_vgpr((int)c3_base) & 0xff;  // the temperature index, as the Philox counter holds it
+      const int group_threads = wide ? ((T + 63) & ~63) : 64;
+      float *const rows = s_dyn + (wide ? 0 : (tid_s >> 6) * (64 * (DP + 2)));
+      float *const s_l = rows + group_threads * DP;
+      float *const s_u = s_l + group_threads;
+      const int base = live ? slot - t : 0;            // slot of temperature 0 of this thread's ladder
       // src = slot whose post-MH vector ends up at this thread's temperature
       int src = slot;
       float my_l = lp_mh;
@@ -373,13 +372,13 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       // commit MH move and swap in one pass: every thread publishes its post-MH vector as its slab row, then
       // fetches the row of slot `src` (rows exchanged through LDS: 2 LDS ops per dimension, no HBM)
       {
-        float *my_row = slab + row_in_slab * D;
+        float *my_row = rows + slot * D;
 #pragma unroll
         for (int d = 0; d < DP; ++d)
           if (d < D) my_row[d] = acc ? y[d] : x[d];
         sync_group();
         const int Dr = fresh_dim<EXACT>(D0);  // generic widths: fresh d < dim compares instead of 2*DP live masks
-        const float *src_row = slab + (src - slab_slot0) * Dr;
+        const float *src_row = rows + src * Dr;
 #pragma unroll
         for (int d = 0; d < DP; ++d) {
           if (d < Dr) {
@@ -424,26 +423,30 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     // everything is recomputed from opaque copies so that nothing of the prologue stays live across the step loop
     const int T2 = fresh_dim<false>(T), D2 = EXACT ? DP : fresh_dim<false>(D0), cpw2 = fresh_dim<false>(cpw);
     const bool wide2 = T2 > 64;
-    const long long c0 = wide2 ? (long long)blockIdx.x : ((long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * cpw2;
-    float *const slab2 = wide2 ? &s_stage[0][0] : s_stage[threadIdx.x >> 6];
-    const long long live_chains = wide2 ? 1 : ((a.n_chains - c0 < cpw2) ? (a.n_chains - c0) : cpw2);
+    const int tid2 = wide2 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    float *const rows2 = s_dyn + (wide2 ? 0 : (int)(threadIdx.x >> 6) * (64 * (DP + 2)));
+    const long long c0 = (wide2 ? (long long)blockIdx.x : (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * cpw2;
+    const long long live_chains = (a.n_chains - c0 < cpw2) ? (a.n_chains - c0) : cpw2;
     const int stage_total = (int)live_chains * T2 * D2;
     const long long stage_g0 = c0 * T2 * (long long)D2;
     c0_out = c0;
     sync_group();  // the last swap's row reads are done before the rows are overwritten
     if (live) {
-      float *row = slab2 + (wide2 ? (int)threadIdx.x : (int)(threadIdx.x & 63)) * D2;
+      float *row = rows2 + tid2 * D2;
 #pragma unroll
       for (int d = 0; d < DP; ++d)
         if (d < D2) row[d] = x[d];
     }
     sync_group();
     float *__restrict__ gs = a.state + stage_g0;
-    const int nthr = wide2 ? kBlockThreads : 64, tid = wide2 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
-    stage_copy(gs, slab2, stage_total, tid, nthr);
+    const int nthr = wide2 ? ((T2 + 63) & ~63) : 64;
+    stage_copy(gs, rows2, stage_total, tid2, nthr);
   }
   if (live) {
-    const long long rep = c0_out * fresh_dim<false>(T) + opaque_vgpr(rep_in_group);
+    const int tid_o = opaque_vgpr((int)threadIdx.x);
+    const int T_o = fresh_dim<false>(T);
+    const long long rep = c0_out * T_o + (T_o > 64 ? tid_o : (tid_o & 63));  // live: replica index in group == tid
+    const int t = opaque_vgpr((int)c3_base) & 0xff;
     a.logp[rep] = lp;
     if (a.n_accept != nullptr) a.n_accept[rep] += (long long)n_acc;
     if (a.sq_jump != nullptr) a.sq_jump[rep] += sq;

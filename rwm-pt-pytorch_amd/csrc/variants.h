@@ -49,12 +49,26 @@ struct TargetVariants {
 
 template <class Target, class Proposal, int DP, bool EXACT>
 hipError_t launch_run(const KArgs &a, unsigned grid, bool full, hipStream_t stream) {
+  // narrow ladders: four independent one-wave groups per workgroup; wide ones (n_temps > 64): as many waves as
+  // the ladder needs
+  const unsigned block = a.n_temps > 64 ? (unsigned)((a.n_temps + 63) & ~63) : (unsigned)kBlockThreads;
+  const unsigned lds = step_kernel_lds_bytes((int)block, DP);
+  auto kfull = ptrwm_step_kernel<Target, Proposal, DP, EXACT, true>;
+  auto kprod = ptrwm_step_kernel<Target, Proposal, DP, EXACT, false>;
+  if (lds > 48u * 1024u) {
+    // above the default dynamic-LDS allowance (wide ladders at large dim): raise it once per kernel
+    static const hipError_t raised = [&] {
+      const int cap = (int)step_kernel_lds_bytes(kBlockThreads, DP);
+      hipError_t e = hipFuncSetAttribute((const void *)kfull, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)kprod, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      return e;
+    }();
+    if (raised != hipSuccess) return raised;
+  }
   if (full)
-    hipLaunchKernelGGL((ptrwm_step_kernel<Target, Proposal, DP, EXACT, true>), dim3(grid), dim3(kBlockThreads), 0,
-                       stream, a);
+    hipLaunchKernelGGL(kfull, dim3(grid), dim3(block), lds, stream, a);
   else
-    hipLaunchKernelGGL((ptrwm_step_kernel<Target, Proposal, DP, EXACT, false>), dim3(grid), dim3(kBlockThreads), 0,
-                       stream, a);
+    hipLaunchKernelGGL(kprod, dim3(grid), dim3(block), lds, stream, a);
   return hipGetLastError();
 }
 
