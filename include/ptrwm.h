@@ -187,6 +187,25 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
 int32_t ptrwm_swap_sweep(const ptrwm_run_args *args, int32_t dim, int64_t event_index, int32_t rng_stream,
                          void *stream);
 
+/* Split step, for target densities the library has no kernel for (a user-defined
+ * TorchTargetDistribution.log_density: SURVEY 8b "anything unrecognised"; the reference calls target.log_density on
+ * the proposals inside step(), pt_rwm_gpu_optimized.py:551, rwm_gpu_optimized.py:289-336).  One step = three calls:
+ *   1. ptrwm_split_propose: for step args->step0, proposals[c,t,:] = state[c,t,:] + increment and
+ *      accept_u[c,t] = the step's accept uniform - the same Philox words (or ext_prop [n_chains, n_temps, raw] /
+ *      ext_u [n_chains, n_temps] of THIS step) and the same arithmetic as ptrwm_run;
+ *   2. the caller evaluates logp_proposed[c,t] = log_density(proposals[c,t,:]) on the device, any way it likes;
+ *   3. ptrwm_split_accept: Metropolis rule, state / logp / statistics update and, when this step's step_counter is a
+ *      swap step, the swap event (ext_swap_u [n_chains, n_temps-1] of THIS event in external-randoms mode) - exactly
+ *      what ptrwm_run does for the step.  Reads from `args`: everything ptrwm_run reads except n_steps and the
+ *      trace fields (accept_flags, if set, is [n_chains, n_temps] for this step).
+ * `proposals` [n_chains, n_temps, dim] and `accept_u` [n_chains, n_temps] are device scratch owned by the caller;
+ * after ptrwm_split_accept `proposals` holds the states from before the step.  Driven with ptrwm_logdensity as the
+ * density, a split step reproduces ptrwm_run bit for bit (tests/test_gpu_engine_parity.py). */
+int32_t ptrwm_split_propose(const ptrwm_proposal_desc *proposal, const ptrwm_run_args *args, int32_t dim,
+                            float *proposals, float *accept_u, void *stream);
+int32_t ptrwm_split_accept(const ptrwm_run_args *args, int32_t dim, float *proposals, const float *accept_u,
+                           const float *logp_proposed, void *stream);
+
 /* out[i] = log_density(x[i, :]) for i < n; x is device [n, dim], out device [n]. */
 int32_t ptrwm_logdensity(const ptrwm_target_desc *target, const float *x, float *out, int64_t n,
                          void *stream);

@@ -16,6 +16,7 @@ invariant to how replicas are sharded over GPUs.
 """
 from __future__ import annotations
 
+import warnings
 from typing import Optional, Sequence
 
 import numpy as np
@@ -57,7 +58,20 @@ class EngineRun:
                 "The PT-RWM engine runs only on a ROCm GPU (device='cuda'); there is no CPU fallback. "
                 f"Requested device: {device}"
             )
-        self.target = target_dist.engine_target()
+        # Targets the fused kernel knows describe themselves (engine_target).  Any other TorchTargetDistribution - a
+        # user-defined density, a dense-covariance Gaussian - runs in split steps: HIP kernels for proposal, accept and
+        # swap (same Philox streams, same arithmetic) around one device-side `log_density` call per step
+        # (the reference calls target.log_density on the proposals the same way, pt_rwm_gpu_optimized.py:551).
+        self.density_fn = None
+        try:
+            self.target = target_dist.engine_target()
+        except (NotImplementedError, AttributeError):
+            if not callable(getattr(target_dist, "log_density", None)):
+                raise TypeError(f"{type(target_dist).__name__} has neither engine_target() nor log_density()")
+            self.target = None
+            self.density_fn = target_dist.log_density
+            warnings.warn(f"{type(target_dist).__name__} has no fused kernel: running split steps (HIP proposal / "
+                          "accept / swap kernels around its log_density, three launches per step).")
         self.proposal = proposal
         self.dim, self.n_temps, self.n_replicas = dim, n_temps, n_replicas
         self.device = device
@@ -72,7 +86,7 @@ class EngineRun:
         x0 = torch.as_tensor(np.asarray(initial_state), dtype=torch.float32).to(device)
         # every temperature (and replica) starts from the same point (pt_rwm_gpu_optimized.py:478-484)
         self.state = x0.expand(n_replicas, n_temps, dim).contiguous()
-        self.logp = ptrwm_hip.logdensity(self.target, self.state.view(-1, dim)).view(n_replicas, n_temps).contiguous()
+        self.logp = self._density(self.state.view(-1, dim)).view(n_replicas, n_temps).contiguous()
         shape = (n_replicas, n_temps)
         self.n_accept = torch.zeros(shape, device=device, dtype=torch.int64)
         self.sq_jump = torch.zeros(shape, device=device, dtype=torch.float64)
@@ -86,6 +100,18 @@ class EngineRun:
             chain_offset=self.chain_offset, n_accept=self.n_accept, sq_jump=self.sq_jump,
             swap_accept=self.swap_accept, last_swap_ordinal=self.last_ord)
 
+    def _density(self, rows: torch.Tensor) -> torch.Tensor:
+        """log-density of every row [n, dim] -> float32 [n] on the device."""
+        if self.density_fn is None:
+            return ptrwm_hip.logdensity(self.target, rows)
+        out = self.density_fn(rows)
+        if not torch.is_tensor(out) or out.shape != (rows.shape[0],):
+            raise ValueError("log_density must map a [n, dim] device tensor to a [n] tensor")
+        if not out.is_cuda:
+            raise RuntimeError("log_density returned a CPU tensor: a split-step target must evaluate on the GPU "
+                               "(there is no CPU path)")
+        return out.to(torch.float32).contiguous()
+
     # ---- stepping ---------------------------------------------------------------------------
     def traced_rows(self, n_steps: int, every: int) -> int:
         """Rows a trace with thinning period `every` receives from the next n_steps steps."""
@@ -96,12 +122,32 @@ class EngineRun:
         """Enqueue n_steps fused steps (no host synchronisation)."""
         if n_steps <= 0:
             return
+        if self.density_fn is not None:
+            self._advance_split(n_steps, trace, trace_logp, trace_row0, max(1, int(trace_every)))
+            return
         if trace is None and trace_logp is None:
             self._plan.launch(self.steps_done, n_steps, swap_event_offset=self.manual_sweeps)
         else:
             self._plan.launch(self.steps_done, n_steps, trace=trace, trace_logp=trace_logp, trace_row0=trace_row0,
                               trace_every=trace_every, swap_event_offset=self.manual_sweeps)
         self.steps_done += n_steps
+
+    def _advance_split(self, n_steps, trace, trace_logp, trace_row0, trace_every) -> None:
+        """n_steps split steps; traced steps (step_counter a multiple of trace_every) are copied with torch."""
+        C, T, D = self.n_replicas, self.n_temps, self.dim
+        row = trace_row0
+        for _ in range(n_steps):
+            s = self.steps_done
+            props = self._plan.split_propose(s)
+            lp_new = self._density(props.view(-1, D)).view(C, T)
+            self._plan.split_accept(s, lp_new, swap_event_offset=self.manual_sweeps)
+            self.steps_done += 1
+            if trace is not None and self.steps_done % trace_every == 0:
+                tc, tt = trace.shape[1], trace.shape[2]
+                trace[row] = self.state[:tc, :tt]
+                if trace_logp is not None:
+                    trace_logp[row] = self.logp[:tc, :tt]
+                row += 1
 
     def swap_sweep(self) -> None:
         """One stand-alone swap event over the current states (`_attempt_all_swaps()` called on its own,

@@ -125,6 +125,8 @@ struct SweepArgs {
   float *state, *logp;
   const float *beta, *ext_swap_u;
   long long *swap_accept, *last_swap_ordinal;
+  const float *prev;  // split step: states before the step's MH move, or NULL
+  double *sq_jump;    // split step: += |final - prev|^2 per replica (the fused kernel's swap-step jump), or NULL
   long long chain_offset, event_index;
   unsigned long long step;
   int n_temps, dim, swap_mode, swap_order, rng_stream, chunk;
@@ -164,6 +166,8 @@ __global__ void __launch_bounds__(256) swap_sweep_kernel(const SweepArgs a) {
   if (live) s_src[tid] = src;
   __syncthreads();
   float *gs = a.state + chain * T * (long long)D;
+  const float *prev = a.prev != nullptr ? a.prev + chain * T * (long long)D : nullptr;
+  float j2 = 0.0f;  // |final - prev|^2 of this thread's replica, accumulated in dimension order like the fused kernel
   for (int c0 = 0; c0 < D; c0 += a.chunk) {
     const int w = (D - c0 < a.chunk) ? D - c0 : a.chunk;
     for (int i = tid; i < T * w; i += nthr) {
@@ -175,11 +179,18 @@ __global__ void __launch_bounds__(256) swap_sweep_kernel(const SweepArgs a) {
       const int tt = i / w, dd = i - tt * w;
       gs[tt * D + c0 + dd] = s_rows[s_src[tt] * w + dd];
     }
+    if (live && prev != nullptr) {
+      for (int dd = 0; dd < w; ++dd) {
+        const float dl = sub_rn(s_rows[src * w + dd], prev[t * D + c0 + dd]);
+        j2 = fmaf(dl, dl, j2);
+      }
+    }
     __syncthreads();
   }
   if (live) {
     const long long rep = chain * T + t;
     a.logp[rep] = my_l;
+    if (a.sq_jump != nullptr) a.sq_jump[rep] += (double)j2;
     if (pair_acc) {
       if (a.swap_accept != nullptr) a.swap_accept[rep] += 1;
       if (a.last_swap_ordinal != nullptr) {
@@ -189,6 +200,60 @@ __global__ void __launch_bounds__(256) swap_sweep_kernel(const SweepArgs a) {
       }
     }
   }
+}
+
+// Split step, second half: Metropolis rule on caller-evaluated log-densities, one thread per replica.  `proposals`
+// comes back holding the pre-step states (the swap event of this step, if any, needs them for the jump distance).
+struct SplitAcceptArgs {
+  float *state, *logp, *proposals;
+  const float *beta, *accept_u, *logp_new;
+  long long *n_accept;
+  double *sq_jump;
+  unsigned char *accept_flags;
+  long long n_reps;
+  int n_temps, dim, count_on, swap_due;
+};
+
+__global__ void __launch_bounds__(256) split_accept_kernel(const SplitAcceptArgs a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_reps) return;
+  const int t = (int)(i % a.n_temps);
+  const float lp = a.logp[i], lp_new = a.logp_new[i];
+  const bool acc = mh_accept(a.beta[t], lp_new, lp, a.accept_u[i]);
+  float *__restrict__ x = a.state + i * a.dim;
+  float *__restrict__ y = a.proposals + i * a.dim;
+  float j2 = 0.0f;
+  for (int d = 0; d < a.dim; ++d) {
+    const float xo = x[d], yn = y[d];
+    const float dl = sub_rn(yn, xo);
+    j2 = fmaf(dl, dl, j2);
+    if (acc) x[d] = yn;
+    y[d] = xo;
+  }
+  if (acc) a.logp[i] = lp_new;
+  if (a.accept_flags != nullptr) a.accept_flags[i] = acc ? 1 : 0;
+  if (a.count_on) {
+    if (a.n_accept != nullptr) a.n_accept[i] += acc ? 1 : 0;
+    // a swap step's jump (MH move and swap together) is added by the sweep that follows
+    if (a.sq_jump != nullptr && !a.swap_due && acc) a.sq_jump[i] += (double)j2;
+  }
+}
+
+template <template <int> class Proposal>
+static hipError_t launch_split_propose(int wi, const float *state, float *proposals, float *accept_u, long long n_chains,
+                                       long long chain_offset, unsigned long long step, int D, int T, const float *ts,
+                                       const PParams &pp, const float *ext_raw, const float *ext_u, int n_raw,
+                                       unsigned k0, unsigned k1, hipStream_t st) {
+  const long long tot = n_chains * T;
+  const dim3 grid((unsigned)((tot + kBlockThreads - 1) / kBlockThreads)), block(kBlockThreads);
+  int idx = 0;
+#define PTRWM_X_SPLIT(W, E)                                                                                       \
+  if (wi == idx++)                                                                                                \
+    hipLaunchKernelGGL((ptrwm_split_propose_kernel<Proposal<W>, W>), grid, block, 0, st, state, proposals,       \
+                       accept_u, n_chains, chain_offset, step, D, T, ts, pp, ext_raw, ext_u, n_raw, k0, k1);
+  PTRWM_WIDTHS(PTRWM_X_SPLIT)
+#undef PTRWM_X_SPLIT
+  return hipGetLastError();
 }
 
 template <template <int> class Proposal>
@@ -204,6 +269,34 @@ static hipError_t launch_propose(int wi, float *out, long long n, int D, int T, 
   PTRWM_WIDTHS(PTRWM_X_PROPOSE)
 #undef PTRWM_X_PROPOSE
   return hipGetLastError();
+}
+
+// One swap event over the current states (ptrwm_swap_sweep, and the swap step of ptrwm_split_accept).
+static int32_t launch_sweep(const ptrwm_run_args *args, int32_t dim, int64_t event_index, int32_t rng_stream,
+                            const float *prev, double *sq_jump, hipStream_t stream) {
+  SweepArgs a;
+  a.state = args->state;
+  a.logp = args->logp;
+  a.beta = args->beta;
+  a.ext_swap_u = args->ext_swap_u;
+  a.swap_accept = (long long *)args->swap_accept;
+  a.last_swap_ordinal = (long long *)args->last_swap_ordinal;
+  a.prev = prev;
+  a.sq_jump = sq_jump;
+  a.chain_offset = args->chain_offset;
+  a.event_index = event_index;
+  a.step = (unsigned long long)args->step0;
+  a.n_temps = args->n_temps;
+  a.dim = dim;
+  a.swap_mode = args->swap_mode;
+  a.swap_order = args->swap_order;
+  a.rng_stream = rng_stream;
+  a.chunk = kSweepLdsFloats / args->n_temps;  // >= 32 columns per pass
+  a.k0 = (unsigned)(args->seed & 0xffffffffull);
+  a.k1 = (unsigned)(args->seed >> 32);
+  const unsigned block = (unsigned)((args->n_temps + 63) / 64 * 64);
+  hipLaunchKernelGGL(swap_sweep_kernel, dim3((unsigned)args->n_chains), dim3(block), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? PTRWM_OK : PTRWM_E_LAUNCH;
 }
 
 }  // namespace ptrwm
@@ -369,27 +462,87 @@ int32_t ptrwm_swap_sweep(const ptrwm_run_args *args, int32_t dim, int64_t event_
   if (args->swap_order != PTRWM_ORDER_SEQUENTIAL && args->swap_order != PTRWM_ORDER_EVEN_ODD) return PTRWM_E_ARG;
   if (args->n_chains == 0 || args->n_temps == 1) return PTRWM_OK;  // nothing to exchange
   if (args->state == nullptr || args->logp == nullptr || args->beta == nullptr) return PTRWM_E_NULL;
-  SweepArgs a;
+  return launch_sweep(args, dim, event_index, rng_stream, nullptr, nullptr, (hipStream_t)stream);
+}
+
+static int32_t split_common_checks(const ptrwm_run_args *args, int32_t dim) {
+  if (args == nullptr) return PTRWM_E_NULL;
+  if (args->struct_size != sizeof(ptrwm_run_args)) return PTRWM_E_STRUCT;
+  if (dim < 1 || dim > PTRWM_MAX_DIM) return PTRWM_E_DIM;
+  if (args->n_temps < 1 || args->n_temps > PTRWM_MAX_TEMPS) return PTRWM_E_TEMPS;
+  if (args->n_chains < 0 || args->n_chains > 0x7fffffffll || args->step0 < 0 || args->burn_in < 0 ||
+      args->swap_every < 1)
+    return PTRWM_E_ARG;
+  if (args->swap_mode != PTRWM_SWAP_EXCHANGE && args->swap_mode != PTRWM_SWAP_REFERENCE_COPY) return PTRWM_E_ARG;
+  if (args->swap_order != PTRWM_ORDER_SEQUENTIAL && args->swap_order != PTRWM_ORDER_EVEN_ODD) return PTRWM_E_ARG;
+  return PTRWM_OK;
+}
+
+int32_t ptrwm_split_propose(const ptrwm_proposal_desc *proposal, const ptrwm_run_args *args, int32_t dim,
+                            float *proposals, float *accept_u, void *stream) {
+  if (proposal == nullptr) return PTRWM_E_NULL;
+  if (int rc = split_common_checks(args, dim)) return rc;
+  if (proposal->kind < 0 || proposal->kind >= PTRWM_PROPOSAL_COUNT) return PTRWM_E_KIND;
+  if (args->n_chains == 0) return PTRWM_OK;
+  if (args->state == nullptr || proposals == nullptr || accept_u == nullptr || proposal->temp_scale == nullptr)
+    return PTRWM_E_NULL;
+  if (proposal->kind == PTRWM_PROPOSAL_LAPLACE && proposal->dim_scale == nullptr) return PTRWM_E_NULL;
+  if (args->ext_prop != nullptr && args->ext_u == nullptr) return PTRWM_E_NULL;
+  const int dpi = width_index_for_dim(dim);
+  if (dpi < 0) return PTRWM_E_DIM;
+  PParams pp;
+  pp.dim_scale = proposal->dim_scale;
+  pp.inv_dim = proposal->inv_dim;
+  const unsigned k0 = (unsigned)(args->seed & 0xffffffffull), k1 = (unsigned)(args->seed >> 32);
+  const int n_raw = ptrwm_ext_raw_per_step(proposal->kind, dim);
+  hipError_t err;
+#define PTRWM_SPLIT_CALL(P)                                                                                          \
+  launch_split_propose<P>(dpi, args->state, proposals, accept_u, args->n_chains, args->chain_offset,                 \
+                          (unsigned long long)args->step0, dim, args->n_temps, proposal->temp_scale, pp,             \
+                          args->ext_prop, args->ext_prop != nullptr ? args->ext_u : nullptr, n_raw, k0, k1,         \
+                          (hipStream_t)stream)
+  switch (proposal->kind) {
+    case PTRWM_PROPOSAL_NORMAL: err = PTRWM_SPLIT_CALL(NormalProposal); break;
+    case PTRWM_PROPOSAL_LAPLACE: err = PTRWM_SPLIT_CALL(LaplaceProposal); break;
+    default: err = PTRWM_SPLIT_CALL(UniformRadiusProposal); break;
+  }
+#undef PTRWM_SPLIT_CALL
+  return err == hipSuccess ? PTRWM_OK : PTRWM_E_LAUNCH;
+}
+
+int32_t ptrwm_split_accept(const ptrwm_run_args *args, int32_t dim, float *proposals, const float *accept_u,
+                           const float *logp_proposed, void *stream) {
+  if (int rc = split_common_checks(args, dim)) return rc;
+  if (args->n_chains == 0) return PTRWM_OK;
+  if (args->state == nullptr || args->logp == nullptr || args->beta == nullptr || proposals == nullptr ||
+      accept_u == nullptr || logp_proposed == nullptr)
+    return PTRWM_E_NULL;
+  const long long sc = args->step0 + 1;  // step_counter of this step
+  const bool count_on = sc > args->burn_in;
+  const bool swap_due = args->n_temps > 1 && count_on && (sc % args->swap_every == 0);
+  const bool ext = args->ext_prop != nullptr;
+  if (swap_due && ext && args->ext_swap_u == nullptr) return PTRWM_E_NULL;
+  SplitAcceptArgs a;
   a.state = args->state;
   a.logp = args->logp;
+  a.proposals = proposals;
   a.beta = args->beta;
-  a.ext_swap_u = args->ext_swap_u;
-  a.swap_accept = (long long *)args->swap_accept;
-  a.last_swap_ordinal = (long long *)args->last_swap_ordinal;
-  a.chain_offset = args->chain_offset;
-  a.event_index = event_index;
-  a.step = (unsigned long long)args->step0;
+  a.accept_u = accept_u;
+  a.logp_new = logp_proposed;
+  a.n_accept = (long long *)args->n_accept;
+  a.sq_jump = args->sq_jump;
+  a.accept_flags = args->accept_flags;
+  a.n_reps = args->n_chains * (long long)args->n_temps;
   a.n_temps = args->n_temps;
   a.dim = dim;
-  a.swap_mode = args->swap_mode;
-  a.swap_order = args->swap_order;
-  a.rng_stream = rng_stream;
-  a.chunk = kSweepLdsFloats / args->n_temps;  // >= 32 columns per pass
-  a.k0 = (unsigned)(args->seed & 0xffffffffull);
-  a.k1 = (unsigned)(args->seed >> 32);
-  const unsigned block = (unsigned)((args->n_temps + 63) / 64 * 64);
-  hipLaunchKernelGGL(swap_sweep_kernel, dim3((unsigned)args->n_chains), dim3(block), 0, (hipStream_t)stream, a);
-  return hipGetLastError() == hipSuccess ? PTRWM_OK : PTRWM_E_LAUNCH;
+  a.count_on = count_on ? 1 : 0;
+  a.swap_due = swap_due ? 1 : 0;
+  hipLaunchKernelGGL(split_accept_kernel, dim3((unsigned)((a.n_reps + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  if (hipGetLastError() != hipSuccess) return PTRWM_E_LAUNCH;
+  if (!swap_due) return PTRWM_OK;
+  // the swap event of this step: event number as ptrwm_run counts them, swap uniforms from the fused kernel's stream
+  const long long ev = sc / args->swap_every - args->burn_in / args->swap_every - 1 + args->swap_event_offset;
+  return launch_sweep(args, dim, ev, (int)kStreamSwap, proposals, args->sq_jump, (hipStream_t)stream);
 }
 
 int32_t ptrwm_logdensity(const ptrwm_target_desc *target, const float *x, float *out, int64_t n, void *stream) {

@@ -77,6 +77,14 @@ __device__ __forceinline__ bool swap_accept_test(float u, float log_prob) {
   return (log_prob >= 0.0f) ? (u < 1.0f) : (u < hw_exp(log_prob));
 }
 
+// ultra_fused_mcmc_step_basic (rwm_gpu_optimized.py:9-32) / ultra_fused_parallel_mcmc_step
+// (pt_rwm_gpu_optimized.py:62-84):  r = beta (l' - l);  accept = (r > 0) | (u < exp r).  Shared by the fused step
+// kernel and the split-step accept kernel.
+__device__ __forceinline__ bool mh_accept(float beta_t, float lp_new, float lp, float u_acc) {
+  const float ratio = mul_rn(beta_t, sub_rn(lp_new, lp));
+  return (ratio > 0.0f) || (u_acc < hw_exp(ratio));
+}
+
 // The decision part of one swap event (pt_rwm_gpu_optimized.py:594-633), shared by the fused step kernel and the
 // stand-alone sweep kernel (capi.hip).  In: this thread's temperature t (0 for idle threads), base = slot of
 // temperature 0 of its ladder, slot = base + t, us = its swap uniform, my_l = its log-density; s_l / s_u = the
@@ -316,8 +324,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
 
     // ultra_fused_mcmc_step_basic / ultra_fused_parallel_mcmc_step:
     //   r = beta (l' - l);  accept = (r > 0) | (u < exp r)
-    const float ratio = mul_rn(beta_t, sub_rn(lp_new, lp));
-    const bool acc = (ratio > 0.0f) || (u_acc < hw_exp(ratio));
+    const bool acc = mh_accept(beta_t, lp_new, lp, u_acc);
     const float lp_mh = acc ? lp_new : lp;
     if constexpr (FULL) {
       if (a.full.accept_flags != nullptr && live) a.full.accept_flags[srep] = acc ? 1 : 0;
@@ -500,6 +507,39 @@ __global__ void __launch_bounds__(kBlockThreads) ptrwm_propose_kernel(
 #pragma unroll
   for (int d = 0; d < DP; ++d)
     if (d < D) op[d] = y[d];
+}
+
+// ---- split step, first half: proposals for one step written to HBM (targets evaluated by the caller) ----
+// Same Philox words and the same arithmetic as the fused kernel's Proposal::propose call, so a split step driven
+// with the library's own log-density reproduces ptrwm_run bit for bit.
+template <class Proposal, int DP>
+__global__ void __launch_bounds__(kBlockThreads) ptrwm_split_propose_kernel(
+    const float *__restrict__ state, float *__restrict__ proposals, float *__restrict__ accept_u, long long n_chains,
+    long long chain_offset, unsigned long long step, int D, int T, const float *__restrict__ temp_scale, PParams pp,
+    const float *__restrict__ ext_raw, const float *__restrict__ ext_u, int n_raw_ext, unsigned k0, unsigned k1) {
+  const long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
+  if (i >= n_chains * T) return;
+  const long long chain = i / T;
+  const int t = (int)(i - chain * T);
+  float x[DP], y[DP];
+  const float *__restrict__ xp = state + i * D;
+#pragma unroll
+  for (int d = 0; d < DP; ++d) x[d] = (d < D) ? xp[d] : 0.0f;
+  const unsigned long long gchain = (unsigned long long)(chain_offset + chain);
+  RngCtx rc;
+  rc.c0hi = (uint32_t)(step >> 32) << 16;
+  rc.c1 = (uint32_t)step;
+  rc.c2 = (uint32_t)gchain;
+  rc.c3 = (uint32_t)t | ((uint32_t)(gchain >> 32) << 12) | (kStreamMH << 8);
+  rc.k0 = k0;
+  rc.k1 = k1;
+  const float *er = ext_raw != nullptr ? ext_raw + i * n_raw_ext : nullptr;
+  const float u = Proposal::propose(y, x, D, temp_scale[t], pp, rc, er, ext_u != nullptr ? ext_u[i] : 0.0f);
+  float *__restrict__ op = proposals + i * D;
+#pragma unroll
+  for (int d = 0; d < DP; ++d)
+    if (d < D) op[d] = y[d];
+  accept_u[i] = u;
 }
 
 }  // namespace ptrwm

@@ -118,6 +118,10 @@ SYMBOLS = {
     "ptrwm_has_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "ptrwm_run": (C.c_int32, [C.POINTER(TargetDesc), C.POINTER(ProposalDesc), C.POINTER(RunArgs), C.c_void_p]),
     "ptrwm_swap_sweep": (C.c_int32, [C.POINTER(RunArgs), C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
+    "ptrwm_split_propose": (
+        C.c_int32, [C.POINTER(ProposalDesc), C.POINTER(RunArgs), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ptrwm_split_accept": (
+        C.c_int32, [C.POINTER(RunArgs), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ptrwm_logdensity": (C.c_int32, [C.POINTER(TargetDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ptrwm_propose": (
         C.c_int32,
@@ -307,7 +311,7 @@ class RunPlan:
         if state.dim() != 3:
             raise ValueError("state must be [n_chains, n_temps, dim]")
         Cn, T, D = state.shape
-        if D != target.dim:
+        if target is not None and D != target.dim:
             raise ValueError(f"state dim {D} != target dim {target.dim}")
         if tuple(logp.shape) != (Cn, T) or beta.numel() != T or proposal.temp_scale.numel() != T:
             raise ValueError("logp/beta/temp_scale shapes do not match state")
@@ -337,9 +341,10 @@ class RunPlan:
         a.swap_order = swap_order
         a.seed = seed & (2**64 - 1)
         self._a = a
-        self._t = target.desc()
+        # target None: a plan for split steps only (the caller evaluates the density, see split_propose)
+        self._t = target.desc() if target is not None else None
         self._p = proposal.desc()
-        self._refs = (self._t, self._p, C.byref(self._t), C.byref(self._p), C.byref(a))
+        self._refs = (self._t, self._p, C.byref(self._t) if target is not None else None, C.byref(self._p), C.byref(a))
         self._keep = (target, proposal, state, logp, beta, n_accept, sq_jump, swap_accept, last_swap_ordinal)
         self._plain = True  # no per-launch buffers set in _a
 
@@ -359,6 +364,8 @@ class RunPlan:
         swap_event_offset: int = 0,  # stand-alone sweeps (swap_sweep) performed before this launch
     ) -> None:
         """Enqueue ``n_steps`` fused MH(+swap) steps, starting at global step ``step0``, on the current stream."""
+        if self._t is None:
+            raise RuntimeError("this plan has no target description: use split_propose / split_accept")
         a = self._a
         a.step0 = step0
         a.n_steps = n_steps
@@ -394,6 +401,59 @@ class RunPlan:
         rc = self._lib.ptrwm_run(self._refs[2], self._refs[3], self._refs[4], _stream(self.device))
         if rc != 0:
             raise PTRWMError(rc, "ptrwm_run")
+
+    def _split_buffers(self):
+        if getattr(self, "_split", None) is None:
+            Cn, T, D = self.shape
+            self._split = (torch.empty(Cn, T, D, device=self.device, dtype=torch.float32),
+                           torch.empty(Cn, T, device=self.device, dtype=torch.float32))
+        return self._split
+
+    def split_propose(self, step: int, ext_prop: Optional[torch.Tensor] = None,
+                      ext_u: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """First half of a split step (ptrwm_split_propose): returns the proposals [C, T, D] of global step ``step``
+        (a buffer owned by the plan, overwritten by the next call).  The caller evaluates its log-density on them and
+        passes the result to ``split_accept``."""
+        a = self._a
+        Cn, T, D = self.shape
+        props, acc_u = self._split_buffers()
+        a.step0 = step
+        a.ext_prop = _opt(ext_prop, "ext_prop", torch.float32)
+        a.ext_u = _opt(ext_u, "ext_u", torch.float32)
+        if ext_prop is not None:
+            raw = ext_raw_per_step(self.proposal_kind, D)
+            if tuple(ext_prop.shape) != (Cn, T, raw) or ext_u is None or tuple(ext_u.shape) != (Cn, T):
+                raise ValueError("ext_prop / ext_u of one step must be [n_chains, n_temps, raw] / [n_chains, n_temps]")
+        self._plain = False
+        rc = self._lib.ptrwm_split_propose(self._refs[3], self._refs[4], D, props.data_ptr(), acc_u.data_ptr(),
+                                           _stream(self.device))
+        if rc != 0:
+            raise PTRWMError(rc, "ptrwm_split_propose")
+        return props
+
+    def split_accept(self, step: int, logp_proposed: torch.Tensor, ext_swap_u: Optional[torch.Tensor] = None,
+                     accept_flags: Optional[torch.Tensor] = None, swap_event_offset: int = 0) -> None:
+        """Second half (ptrwm_split_accept): Metropolis rule on ``logp_proposed`` [C, T], updates, and the swap event
+        when ``step`` is a swap step."""
+        a = self._a
+        Cn, T, D = self.shape
+        props, acc_u = self._split_buffers()
+        if tuple(logp_proposed.shape) != (Cn, T):
+            raise ValueError(f"logp_proposed must be [{Cn}, {T}]")
+        if ext_swap_u is not None and tuple(ext_swap_u.shape) != (Cn, T - 1):
+            raise ValueError(f"ext_swap_u of one event must be [{Cn}, {T - 1}]")
+        if accept_flags is not None and tuple(accept_flags.shape) != (Cn, T):
+            raise ValueError(f"accept_flags of one step must be [{Cn}, {T}]")
+        a.step0 = step
+        a.swap_event_offset = swap_event_offset
+        a.ext_swap_u = _opt(ext_swap_u, "ext_swap_u", torch.float32)
+        a.accept_flags = _opt(accept_flags, "accept_flags", torch.uint8)
+        self._plain = False
+        rc = self._lib.ptrwm_split_accept(self._refs[4], D, props.data_ptr(), acc_u.data_ptr(),
+                                          _require_device(logp_proposed, "logp_proposed", torch.float32),
+                                          _stream(self.device))
+        if rc != 0:
+            raise PTRWMError(rc, "ptrwm_split_accept")
 
     def swap_sweep(self, rng_step: int, event_index: int, rng_stream: int = 2,
                    ext_swap_u: Optional[torch.Tensor] = None) -> None:

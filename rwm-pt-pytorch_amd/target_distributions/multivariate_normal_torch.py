@@ -3,8 +3,8 @@
 Parameter holders with the reference's constructors and names
 (target_distributions/multivariate_normal_torch.py:5-131 MultivariateNormalTorch, :134-295
 ScaledMultivariateNormalTorch); densities are evaluated by the HIP engine (csrc/targets.h DiagGaussian).
-The fused kernel implements the diagonal-covariance case only: a dense covariance is a [D,D] contraction
-per proposal, outside the hot-path scope, and is rejected loudly.
+The fused kernel implements the diagonal-covariance case; a dense covariance is a [D,D] contraction per proposal
+(a library GEMM) and runs through the engine's split steps like any user-defined density.
 """
 import numpy as np
 import torch
@@ -36,17 +36,30 @@ class MultivariateNormalTorch(TorchTargetDistribution):
         return self.name
 
     def engine_target(self):
-        off_diag = self.cov - torch.diag(torch.diagonal(self.cov))
-        if bool((off_diag != 0).any()):
+        if not self._is_diagonal():
             raise NotImplementedError(
                 "MultivariateNormalTorch with a non-diagonal covariance has no fused-kernel implementation "
-                "(a dense [D,D] contraction per proposal is outside the engine's scope)."
+                "(a dense [D,D] contraction per proposal); the samplers run it with split steps."
             )
         return ptrwm_hip.Target(ptrwm_hip.TARGET_DIAG_GAUSSIAN, self.dim, p=(float(self.log_norm_const),), ip=(0,),
                                 vec0=self.mean.contiguous(), vec1=torch.diagonal(self.cov_inv).contiguous())
 
+    def _is_diagonal(self):
+        off_diag = self.cov - torch.diag(torch.diagonal(self.cov))
+        return not bool((off_diag != 0).any())
+
     def log_density(self, x):
-        return self._engine_log_density(x)
+        if self._is_diagonal():
+            return self._engine_log_density(x)
+        # dense covariance (multivariate_normal_torch.py:58-93 in the reference): one [B, D] x [D, D] library GEMM on
+        # the device; the samplers reach it through split steps (ptrwm_split_propose / ptrwm_split_accept)
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(x)
+        x = x.to(device=self.device, dtype=_F32)
+        single = x.dim() == 1
+        c = (x.unsqueeze(0) if single else x) - self.mean
+        out = -0.5 * torch.sum((c @ self.cov_inv) * c, dim=1) + self.log_norm_const
+        return out[0] if single else out
 
     def density(self, x):
         return torch.exp(self.log_density(x))

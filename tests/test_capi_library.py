@@ -124,6 +124,22 @@ def test_validation_needs_no_gpu(engine):
     assert lib.ptrwm_swap_sweep(C.byref(sa), 30, 0, 1, None) == 0  # one temperature: nothing to exchange
     sa.n_temps = 257
     assert lib.ptrwm_swap_sweep(C.byref(sa), 30, 0, 1, None) == -3
+    # split step (user-defined densities): same argument block
+    sp, pd2 = engine.RunArgs(), engine.ProposalDesc()
+    assert lib.ptrwm_split_propose(None, None, 30, None, None, None) == -1
+    assert lib.ptrwm_split_propose(C.byref(pd2), C.byref(sp), 30, None, None, None) == -6
+    sp.struct_size, sp.n_temps, sp.n_chains, sp.swap_every = C.sizeof(engine.RunArgs), 8, 4, 1
+    assert lib.ptrwm_split_propose(C.byref(pd2), C.byref(sp), 0, None, None, None) == -2
+    pd2.kind = 3
+    assert lib.ptrwm_split_propose(C.byref(pd2), C.byref(sp), 30, None, None, None) == -4
+    pd2.kind = 0
+    assert lib.ptrwm_split_propose(C.byref(pd2), C.byref(sp), 30, None, None, None) == -1  # pointers missing
+    assert lib.ptrwm_split_accept(C.byref(sp), 30, None, None, None, None) == -1
+    sp.swap_every = 0
+    assert lib.ptrwm_split_accept(C.byref(sp), 30, None, None, None, None) == -5
+    sp.swap_every, sp.n_chains = 1, 0
+    assert lib.ptrwm_split_accept(C.byref(sp), 30, None, None, None, None) == 0  # empty batch
+    assert lib.ptrwm_split_propose(C.byref(pd2), C.byref(sp), 30, None, None, None) == 0
 
 
 def test_product_refuses_to_run_without_its_library_or_a_gpu(engine, tmp_path):

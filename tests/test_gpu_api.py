@@ -8,7 +8,7 @@ import torch
 import helpers as H
 from algorithms import (ParallelTemperingRWM_GPU_Optimized, RandomWalkMH_GPU_Optimized, geometric_beta_ladder,
                         ultra_fused_mcmc_step_basic)
-from interfaces import MCMCSimulation_GPU
+from interfaces import MCMCSimulation_GPU, TorchTargetDistribution
 from oracle import oracle as O
 from proposal_distributions import LaplaceProposal, NormalProposal, UniformRadiusProposal
 from target_distributions import (EvenRosenbrockTorch, FullRosenbrockTorch, HybridRosenbrockTorch, HypercubeTorch,
@@ -50,9 +50,14 @@ def test_target_classes_reproduce_reference_log_density(device):
         "funnel_d10": NealFunnelTorch(10, device=device),
         "funnel_d1": NealFunnelTorch(1, mu_v=0.5, sigma_v_sq=4.0, device=device),
     }
+    # a dense covariance has no fused kernel (engine_target raises); its density is a device-side library GEMM
+    dense = MultivariateNormalTorch(3, cov=[[1, 0.5, 0], [0.5, 1, 0], [0, 0, 1]], device=device)
     with pytest.raises(NotImplementedError, match="non-diagonal"):
-        MultivariateNormalTorch(3, cov=[[1, 0.5, 0], [0.5, 1, 0], [0, 0, 1]], device=device).log_density(
-            torch.zeros(3, device=device))
+        dense.engine_target()
+    xs = torch.tensor([[0.0, 0.0, 0.0], [1.0, -1.0, 0.5]], device=device)
+    want = torch.distributions.MultivariateNormal(torch.zeros(3), torch.tensor([[1, 0.5, 0], [0.5, 1, 0], [0, 0, 1.0]])
+                                                  ).log_prob(xs.cpu())
+    assert torch.allclose(dense.log_density(xs).cpu(), want, atol=1e-5)
     for key, t in built.items():
         spec, x, ref, meta = G[key]
         assert t.get_name() == meta["name"]
@@ -408,3 +413,53 @@ def test_attempt_all_swaps_standalone(device):
     for _ in range(5):
         alg.step()
     assert alg.num_swap_attempts == alg2_attempts
+
+
+class _BananaTorch(TorchTargetDistribution):
+    """A user-defined density the engine has no kernel for: x0 ~ N(0, 2^2), x1 | x0 ~ N(b (x0^2 - 4), 1), the other
+    coordinates standard normal (so E[x1] = 0, Var[x0] = 4 are known)."""
+
+    def __init__(self, dim, b=0.25, device=None):
+        super().__init__(dim, device)
+        self.b = b
+
+    def get_name(self):
+        return "Banana"
+
+    def density(self, x):
+        return torch.exp(self.log_density(x))
+
+    def log_density(self, x):
+        x = torch.as_tensor(x, device=self.device, dtype=torch.float32)
+        single = x.dim() == 1
+        x = x.unsqueeze(0) if single else x
+        out = -0.5 * (x[:, 0] / 2.0) ** 2 - 0.5 * (x[:, 1] - self.b * (x[:, 0] ** 2 - 4.0)) ** 2 \
+            - 0.5 * (x[:, 2:] ** 2).sum(1)
+        return out[0] if single else out
+
+
+def test_user_defined_target_runs_in_split_steps(device):
+    """A TorchTargetDistribution subclass without a fused kernel: the samplers run it with split steps (HIP proposal /
+    accept / swap kernels around its torch log_density) and say so; its moments come out right."""
+    torch.manual_seed(0)
+    dim = 5
+    target = _BananaTorch(dim, device=device)
+    with pytest.warns(UserWarning, match="split steps"):
+        alg = RandomWalkMH_GPU_Optimized(dim, 1.2, target, burn_in=300, device=device, num_chains=4096, seed=21)
+        alg.generate_samples(900)
+    assert 0.15 < alg.acceptance_rate < 0.6
+    x = alg._run.state[:, 0]  # one draw per chain after 1200 steps
+    assert abs(float(x[:, 0].mean())) < 0.15 and abs(float(x[:, 0].var()) - 4.0) < 0.5
+    assert abs(float(x[:, 1].mean())) < 0.15 and abs(float(x[:, 2:].var()) - 1.0) < 0.1
+    # PT on a dense-covariance Gaussian (library GEMM density): the cold chain has the target's covariance
+    cov = torch.tensor([[1.0, 0.8, 0.0], [0.8, 1.0, 0.3], [0.0, 0.3, 2.0]])
+    mvn = MultivariateNormalTorch(3, cov=cov, device=device)
+    with pytest.warns(UserWarning, match="split steps"):
+        pt = ParallelTemperingRWM_GPU_Optimized(3, 1.0, mvn, beta_ladder=[1.0, 0.5, 0.25], swap_every=5, burn_in=200,
+                                                device=device, num_replicas=4096, seed=5, trace="cold")
+        cold = pt.generate_samples(600)
+    assert cold.shape == (600, 3) and torch.isfinite(cold).all()
+    xs = pt._run.state[:, 0]
+    got = torch.cov(xs.T).cpu()
+    assert torch.allclose(got, cov, atol=0.15)
+    assert 0.2 < pt.swap_acceptance_rate <= 1.0 and pt.num_swap_attempts == (800 // 5 - 200 // 5) * 2 * 4096

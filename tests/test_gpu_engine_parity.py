@@ -627,3 +627,62 @@ def test_standalone_sweep_equals_the_fused_kernels_swap(device):
         assert np.array_equal(got["state"], fused["state"]) and np.array_equal(got["logp"], fused["logp"])
         assert np.array_equal(got["swap_accept"], fused["swap_accept"])
         assert np.array_equal(got["last_swap_ordinal"], fused["last_swap_ordinal"])
+
+
+
+@pytest.mark.parametrize("tkey,pkind,T,pkw", [
+    ("rc15_d30", "Normal", 8, dict(base_variance_scalar=2.38**2 / 30)),
+    ("rc5_d30", "Normal", 12, dict(base_variance_scalar=2.38**2 / 30)),
+    ("even_d30", "Laplace", 5, dict(base_variance_vector=np.full(30, 0.004))),
+    ("tm_d50", "UniformRadius", 16, dict(base_radius=2.4)),
+    ("hyb_5_4", "Normal", 1, dict(base_variance_scalar=0.02)),
+])
+def test_split_step_reproduces_the_fused_kernel(device, tkey, pkind, T, pkw):
+    """ptrwm_split_propose -> (log-density by ptrwm_logdensity) -> ptrwm_split_accept, step by step, equals
+    ptrwm_run bit for bit: states, log-densities and all four statistics, with swaps in every mode and order, from
+    Philox and from external randoms.  (This is the path a user-defined density takes.)"""
+    spec = H.target_spec(tkey)
+    D = spec.dim
+    beta = (0.02 ** (np.arange(T) / max(1, T - 1))).astype(np.float32) if T > 1 else np.ones(1, np.float32)
+    prop = H.proposal_spec(pkind, D, beta, **pkw) if T > 1 else H.proposal_spec(pkind, D, [1.0], single=True, **pkw)
+    Cn, N, burn, se = 9, 36, 5, 4
+    rng = np.random.default_rng(zlib.crc32(f"{tkey}{pkind}".encode()))
+    st0, lp0 = start_state(spec, Cn, T, rng)
+    raw = E.ext_raw_per_step(H.PROPOSAL_KIND[pkind], D)
+    for order, mode, ext in (("sequential", "exchange", False), ("even_odd", "exchange", True),
+                             ("sequential", "reference_copy", True), ("even_odd", "reference_copy", False)):
+        kw = dict(beta=beta, step0=0, burn_in=burn, swap_every=se, seed=123, chain_offset=4,
+                  swap_order=E.SWAP_ORDERS[order], swap_mode=E.SWAP_MODES[mode])
+        ep = eu = es = None
+        if ext:
+            ep = _ext_arrays(rng, pkind, N, Cn, T, raw)
+            eu = rng.random((N, Cn, T)).astype(np.float32)
+            es = rng.random((N // se, Cn, max(T - 1, 1))).astype(np.float32)[:, :, :T - 1] if T > 1 else None
+        fused = gpu_run(spec, prop, device, state=st0, logp=lp0, n_steps=N, ext_prop=ep, ext_u=eu, ext_swap_u=es,
+                        want_flags=True, **kw)
+        # the same run, one split step at a time
+        st, lp = dev_t(st0, device), dev_t(lp0, device).reshape(Cn, T).contiguous()
+        stats = {k: torch.zeros(Cn, T, dtype=(torch.float64 if k == "sq_jump" else torch.int64), device=device)
+                 for k in ("n_accept", "sq_jump", "swap_accept", "last_swap_ordinal")}
+        plan = E.RunPlan(None, prop.engine(device), state=st, logp=lp, beta=dev_t(beta, device), burn_in=burn,
+                         swap_every=se, swap_mode=E.SWAP_MODES[mode], swap_order=E.SWAP_ORDERS[order], seed=123,
+                         chain_offset=4, **stats)
+        tgt = spec.engine(device)
+        flags = torch.zeros(N, Cn, T, dtype=torch.uint8, device=device)
+        ev = 0
+        for s in range(N):
+            props = plan.split_propose(s, ext_prop=None if ep is None else dev_t(ep[s], device),
+                                       ext_u=None if eu is None else dev_t(eu[s], device))
+            lp_new = E.logdensity(tgt, props.view(-1, D)).view(Cn, T)
+            due = T > 1 and (s + 1) > burn and (s + 1) % se == 0
+            plan.split_accept(s, lp_new, accept_flags=flags[s],
+                              ext_swap_u=dev_t(es[ev], device) if (due and es is not None) else None)
+            ev += 1 if due else 0
+        torch.cuda.synchronize()
+        assert np.array_equal(flags.cpu().numpy(), fused["accept_flags"]), (order, mode, ext)
+        assert np.array_equal(st.cpu().numpy(), fused["state"]), (order, mode, ext)
+        assert np.array_equal(lp.cpu().numpy(), fused["logp"])
+        for k, v in stats.items():
+            assert np.array_equal(v.cpu().numpy(), fused[k]), (k, order, mode, ext)
+        if T > 1:
+            assert fused["swap_accept"].sum() > 0
