@@ -40,12 +40,9 @@ class TorchTargetDistribution(ABC):
 
     # ---- HIP engine hook -------------------------------------------------------------------
     def engine_target(self):
-        """Return a `ptrwm_hip.Target` if the fused kernel knows this density, else raise."""
-        raise NotImplementedError(
-            f"{type(self).__name__} has no fused-kernel implementation (engine_target); the HIP "
-            "samplers only accept RoughCarpet, ThreeMixture, Full/Even/Hybrid Rosenbrock, IIDGamma "
-            "and IIDBeta targets."
-        )
+        """Return a `ptrwm_hip.Target` if the fused kernel knows this density, else raise NotImplementedError: the
+        samplers then run the target in split steps (HIP proposal / accept / swap kernels around `log_density`)."""
+        raise NotImplementedError(f"{type(self).__name__} has no fused-kernel implementation (engine_target).")
 
     def _engine_log_density(self, x):
         """Shared `log_density` body: evaluate rows of `x` with the engine's log-density kernel."""
