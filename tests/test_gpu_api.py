@@ -463,3 +463,47 @@ def test_user_defined_target_runs_in_split_steps(device):
     got = torch.cov(xs.T).cpu()
     assert torch.allclose(got, cov, atol=0.15)
     assert 0.2 < pt.swap_acceptance_rate <= 1.0 and pt.num_swap_attempts == (800 // 5 - 200 // 5) * 2 * 4096
+
+
+def test_long_run_statistics_match_the_reference_anchors(device):
+    """North-star parity bound: acceptance rate and ESJD within 1e-3 relative of the REFERENCE (plus the reference's
+    own Monte-Carlo standard error).  tests/golden/reference_anchors.json holds long runs of the real reference's torch
+    samplers (generate_anchors.py: 14 runs each, RoughCarpet dim 30 modes +-15, var 2.38^2/30, burn-in 1000); the
+    engine runs the same schedule over the same horizon on thousands of independent chains."""
+    import json
+    import os
+
+    path = os.path.join(H.GOLDEN, "reference_anchors.json")
+    if not os.path.exists(path):
+        pytest.skip("reference_anchors.json not generated")
+    with open(path) as f:
+        ref = json.load(f)
+    dim, var, burn = 30, ref["var"], ref["burn_in"]
+    target = RoughCarpetDistributionTorch(dim, device=device, mode_centers=[-15.0, 0.0, 15.0])
+
+    def check(name, got, got_se, anchor, rel_bound=1e-3):
+        tol = rel_bound * abs(anchor["mean"]) + 4.0 * (anchor["stderr"] ** 2 + got_se ** 2) ** 0.5
+        assert abs(got - anchor["mean"]) <= tol, (name, got, anchor, tol)
+
+    # RWM: every chain runs the reference's horizon
+    n, chains = ref["rwm"]["steps_per_run"], 4096
+    alg = RandomWalkMH_GPU_Optimized(dim, var, target, burn_in=burn, device=device, num_chains=chains, seed=1)
+    alg._ensure_started()
+    alg._run.advance(burn + n)
+    acc = (alg._run.n_accept[:, 0].double() / n).cpu().numpy()
+    esjd = (alg._run.sq_jump[:, 0] / n).cpu().numpy()
+    check("rwm acceptance", acc.mean(), acc.std(ddof=1) / np.sqrt(chains), ref["rwm"]["acceptance_rate"])
+    check("rwm esjd", esjd.mean(), esjd.std(ddof=1) / np.sqrt(chains), ref["rwm"]["esjd"])
+
+    # PT with the reference's row-copy swap (Q1) and sequential sweep
+    n, lad = ref["pt"]["steps_per_run"], 2048
+    pt = ParallelTemperingRWM_GPU_Optimized(dim, var, target, beta_ladder=ref["pt"]["beta_ladder"],
+                                            swap_every=ref["pt"]["swap_every"], burn_in=burn, device=device,
+                                            num_replicas=lad, seed=2, swap_mode="reference_copy", trace="none")
+    pt._ensure_started()
+    pt._run.advance(burn + n)
+    attempts = pt._run.swap_attempts_per_replica()
+    frac = (pt._run.swap_accept.sum(1).double() / attempts).cpu().numpy()
+    cold = (pt._run.sq_jump[:, 0] / n).cpu().numpy()
+    check("pt swap acceptance", frac.mean(), frac.std(ddof=1) / np.sqrt(lad), ref["pt"]["swap_accept_fraction"])
+    check("pt cold esjd", cold.mean(), cold.std(ddof=1) / np.sqrt(lad), ref["pt"]["cold_esjd"])
