@@ -686,3 +686,36 @@ def test_split_step_reproduces_the_fused_kernel(device, tkey, pkind, T, pkw):
             assert np.array_equal(v.cpu().numpy(), fused[k]), (k, order, mode, ext)
         if T > 1:
             assert fused["swap_accept"].sum() > 0
+
+
+@pytest.mark.parametrize("T,dim", [(200, 100), (256, 104), (130, 64), (65, 50)])
+def test_wide_ladder_with_large_dim_vs_oracle(device, T, dim):
+    """Wide ladders (one workgroup of ceil(T/64) waves) at large dims: more than 48 KB of dynamic LDS per workgroup
+    (256 threads x 106 floats = 106 KB at dim 104), which needs the raised dynamic-LDS allowance."""
+    rng = np.random.default_rng(T + dim)
+    beta = (0.05 ** (np.arange(T) / (T - 1))).astype(np.float32)
+    prop = H.proposal_spec("Normal", dim, beta, base_variance_scalar=2.38**2 / dim)
+    Cn, N = 2, 12
+    # a diagonal Gaussian of this dimension
+    mean = np.linspace(-1.0, 1.0, dim).astype(np.float32)
+    prec = np.linspace(0.5, 2.0, dim).astype(np.float32)
+    cst = float(-0.5 * dim * np.log(2 * np.pi) + 0.5 * np.log(prec.astype(np.float64)).sum())
+    spec = H.TargetSpec(O.TARGET_DIAG_GAUSSIAN, dim, (cst,), (0,), mean, prec, cls="MultivariateNormalTorch")
+    st, lp = start_state(spec, Cn, T, rng)
+    kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=1, swap_every=2,
+              ext_prop=rng.standard_normal((N, Cn, T, dim)).astype(np.float32),
+              ext_u=rng.random((N, Cn, T)).astype(np.float32),
+              ext_swap_u=rng.random((N // 2, Cn, T - 1)).astype(np.float32), want_flags=True)
+    want = O.run(spec.oracle(), prop.oracle(), trace_chains=Cn, trace_temps=T, **kw)
+    got = gpu_run(spec, prop, device, trace_temps=T, **kw)
+    first = H.first_mismatch(got["accept_flags"], want["accept_flags"])
+    upto = N if first is None else first
+    assert upto >= 6
+    assert np.array_equal(got["trace"][:upto], want["trace"][:upto])
+    if first is None:
+        for k in ("n_accept", "swap_accept", "last_swap_ordinal"):
+            assert np.array_equal(got[k], want[k]), k
+    # production (non-trace) variant at the same shape: runs and keeps the log-densities consistent with the states
+    got2 = gpu_run(spec, prop, device, state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=1, swap_every=2, seed=5)
+    chk = O.logdensity(spec.oracle(), got2["state"].reshape(-1, dim), "f64").reshape(Cn, T)
+    assert np.allclose(got2["logp"], chk, rtol=1e-5, atol=1e-3)
