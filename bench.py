@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5", "pt", "rwm"],
                     help="BASELINE.json configs[1..4] (cfg3 = configs[2], the headline); pt = cfg3, rwm = cfg2")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU readings (configs[1], even/odd)")
     return ap.parse_args()
 
 
@@ -224,6 +225,37 @@ def main():
         elapsed = float(t.item())
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
+    # The other single-GPU readings of the same metric, outside the timed region (N = 1 only): BASELINE configs[1]
+    # (RWM, 65 536 chains, one temperature) and configs[2] with the north star's even/odd swap step.
+    others = None
+    if world == 1 and wl == "cfg3" and not args.no_extras:
+        def quick(make):
+            a2 = make()
+            a2._ensure_started()
+            for _ in range(2):
+                a2._run.advance(args.inner)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                a2._run.advance(args.inner)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            return {"value": a2._run.n_replicas * a2._run.n_temps * args.inner / (ms * 1e-3), "kernel_ms": ms}
+
+        others = {
+            "configs[1]: RWM HIP, RoughCarpet dim 30, Normal proposal, 65536 chains x 1 temperature": quick(
+                lambda: RandomWalkMH_GPU_Optimized(dim, 2.38**2 / dim, target, burn_in=0, device=dev, num_chains=C,
+                                                   seed=42)),
+            "configs[2] with swap_order=even_odd": quick(
+                lambda: ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target,
+                                                           beta_ladder=geometric_beta_ladder(T),
+                                                           swap_every=args.swap_every, burn_in=0, device=dev,
+                                                           num_replicas=C, seed=42, trace="none",
+                                                           swap_order="even_odd")),
+        }
+
     # HBM copy probe (the measured copy bandwidth as a second denominator): 1 GiB device-to-device
     copy_gbps = None
     if rank == 0:
@@ -292,6 +324,8 @@ def main():
                 "replicas": summary["n_replicas"],
             },
         }
+        if others is not None:
+            out["other_single_gpu_readings"] = others
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
