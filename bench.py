@@ -87,7 +87,8 @@ def cpu_baseline(dim, temps, seconds):
         "sample": f"NumPy port of algorithms/{'pt_rwm' if temps > 1 else 'rwm'}.py, RoughCarpet dim {dim}, "
                   f"{temps} temperature(s), 1 ladder, {iters} iterations in {dt:.1f} s on one host core",
     }
-    n = max(1, min(os.cpu_count() or 1, 64))
+    # worker pool sized to the host share of one GPU (16 cores on the benchmark boxes), never above the affinity mask
+    n = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
     if n > 1:
         os.environ.setdefault("OMP_NUM_THREADS", "1")
         with mp.get_context("spawn").Pool(n) as pool:

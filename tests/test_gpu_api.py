@@ -507,3 +507,34 @@ def test_long_run_statistics_match_the_reference_anchors(device):
     cold = (pt._run.sq_jump[:, 0] / n).cpu().numpy()
     check("pt swap acceptance", frac.mean(), frac.std(ddof=1) / np.sqrt(lad), ref["pt"]["swap_accept_fraction"])
     check("pt cold esjd", cold.mean(), cold.std(ddof=1) / np.sqrt(lad), ref["pt"]["cold_esjd"])
+
+
+def test_bench_emits_the_contract_line(device):
+    """bench.py as the driver runs it (a child process; N = 1, few steps): exactly one JSON line with the contract's
+    keys, the roofline and cpu_baseline objects, and sane values."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
+                          "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0
+    assert d["value"] > 1e9  # the north star's floor for this configuration on one MI355X
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    units = d["config"]["ladders_per_gpu"] * d["config"]["temps"] * d["config"]["mh_steps_per_launch"]
+    assert abs(d["value"] - units * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-6
