@@ -9,7 +9,7 @@ OUT=/root/repo/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp
 export TMPDIR=/tmp
-BENCH="python3 /root/repo/bench.py --cpu-seconds 0"
+BENCH="python3 /root/repo/bench.py --cpu-seconds 0 --no-extras"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- $BENCH --steps 25 --warmup 3 > "$OUT/kt.log" 2>&1
 echo "kernel trace done"
 for c in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do

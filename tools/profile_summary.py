@@ -31,7 +31,7 @@ shutil.copy(find(os.path.join(out, "kt"), "kernel_stats.csv"), os.path.join(prof
 rows = [r for r in csv.DictReader(open(find(os.path.join(out, "kt"), "kernel_trace.csv"))) if KERNEL in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 with open(os.path.join(prof, f"{tag}_kernel_trace_{KERNEL}.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --cpu-seconds 0 --steps 25 --warmup 3; "
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --cpu-seconds 0 --no-extras --steps 25 --warmup 3; "
             "one line per dispatch of the step kernel\n")
     f.write("dispatch,duration_ns,grid,workgroup,lds_bytes,vgprs,sgprs,scratch\n")
     for i, r in enumerate(rows):
@@ -58,7 +58,7 @@ allc = {}
 for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_GRBM_GUI_ACTIVE", "pmc_SQ"):
     allc.update(counters(os.path.join(out, sub)))
 with open(os.path.join(prof, f"{tag}_pmc_{KERNEL}_cfg3.csv"), "w") as f:
-    f.write("# rocprofv3 --pmc <counter> --output-format csv -- python3 bench.py --cpu-seconds 0 --steps 5 --warmup 1  "
+    f.write("# rocprofv3 --pmc <counter> --output-format csv -- python3 bench.py --cpu-seconds 0 --no-extras --steps 5 --warmup 1  "
             "(one pass per TCC counter; SQ counters in one pass)\n")
     f.write("# kernel: ptrwm_step_kernel<RoughCarpet2<30>, NormalProposal<30>, 30, exact, production>; per dispatch "
             "(65536 ladders x 32 temps x 100 steps)\n")
