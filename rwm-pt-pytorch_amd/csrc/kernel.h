@@ -72,9 +72,11 @@ __device__ __forceinline__ float swap_log_prob(float bj, float bk, float lj, flo
 }
 
 // swap_random < min(1, exp(log_prob))  (:617-621).  torch.min propagates NaN and NaN compares
-// false; v_min_f32 would drop the NaN, so the clamp is written as a select instead.
+// false; v_min_f32 would drop the NaN, so the clamp is a select of the threshold (one compare on the result:
+// selecting between two finished compares costs the compiler four more instructions per pair).
 __device__ __forceinline__ bool swap_accept_test(float u, float log_prob) {
-  return (log_prob >= 0.0f) ? (u < 1.0f) : (u < hw_exp(log_prob));
+  const float threshold = (log_prob >= 0.0f) ? 1.0f : hw_exp(log_prob);  // NaN log_prob -> NaN threshold -> false
+  return u < threshold;
 }
 
 // ultra_fused_mcmc_step_basic (rwm_gpu_optimized.py:9-32) / ultra_fused_parallel_mcmc_step
