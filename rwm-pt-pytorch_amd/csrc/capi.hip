@@ -161,8 +161,9 @@ __global__ void __launch_bounds__(256) swap_sweep_kernel(const SweepArgs a) {
   __syncthreads();
   int src = t;
   bool pair_acc = false;
-  swap_decide(T, t, 0, t, a.swap_mode, a.swap_order, (int)(a.event_index & 1), a.beta, a.beta[t], us, s_l, s_u, my_l, src,
-              pair_acc);
+  __shared__ int s_landed[256];
+  swap_decide(T, t, 0, t, a.swap_mode, a.swap_order, (int)(a.event_index & 1), a.beta, a.beta[t], us, s_l, s_u, s_landed,
+              my_l, src, pair_acc);
   if (live) s_src[tid] = src;
   __syncthreads();
   float *gs = a.state + chain * T * (long long)D;

@@ -26,8 +26,11 @@ namespace ptrwm {
 constexpr int kBlockThreads = PTRWM_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 // dynamic LDS bytes of a step-kernel workgroup of `threads` threads with register width dp: one row of dp floats
-// per thread plus its log-density and swap-uniform slots
-constexpr unsigned step_kernel_lds_bytes(int threads, int dp) { return (unsigned)(threads * (dp + 2)) * 4u; }
+// per thread plus its log-density, swap-uniform and swap-outcome slots
+constexpr int kLdsExtraPerThread = 3;
+constexpr unsigned step_kernel_lds_bytes(int threads, int dp) {
+  return (unsigned)(threads * (dp + kLdsExtraPerThread)) * 4u;
+}
 
 // Arguments only the fixture / trace variant of the kernel (FULL = true) reads.  Keeping them out
 // of the production variant keeps its wave-uniform state inside the 100-odd SGPRs of a wave.
@@ -90,12 +93,13 @@ __device__ __forceinline__ bool mh_accept(float beta_t, float lp_new, float lp, 
 // The decision part of one swap event (pt_rwm_gpu_optimized.py:594-633), shared by the fused step kernel and the
 // stand-alone sweep kernel (capi.hip).  In: this thread's temperature t (0 for idle threads), base = slot of
 // temperature 0 of its ladder, slot = base + t, us = its swap uniform, my_l = its log-density; s_l / s_u = the
-// ladder's published log-densities and uniforms (already synchronised); par = parity of the event (even/odd order).
+// ladder's published log-densities and uniforms (already synchronised), landed = one int of LDS scratch per slot;
+// par = parity of the event (even/odd order).
 // Out: my_l = the log-density that ends up at temperature t, src = the slot whose vector does, pair_acc = pair
 // (t, t+1) accepted (recorded on the thread of temperature t).
 __device__ __forceinline__ void swap_decide(int T, int t, int base, int slot, int swap_mode, int swap_order, int par,
                                             const float *__restrict__ beta, float beta_t, float us, const float *s_l,
-                                            const float *s_u, float &my_l, int &src, bool &pair_acc) {
+                                            const float *s_u, int *landed, float &my_l, int &src, bool &pair_acc) {
   if (swap_order == PTRWM_ORDER_SEQUENTIAL) {
     if (swap_mode == PTRWM_SWAP_EXCHANGE) {
       // The sweep j = 0..T-2 carries one state upward: at pair j the state now at position j (carried) meets
@@ -104,26 +108,26 @@ __device__ __forceinline__ void swap_decide(int T, int t, int base, int slot, in
       // keeps what lands on its own position.
       float car_l = s_l[base];
       int car_i = base;
+#pragma unroll 2
       for (int j = 0; j < T - 1; ++j) {
         const float lk = s_l[base + j + 1];
         const float u = s_u[base + j];
         const float bj = beta[j], bk = beta[j + 1];
         const bool ok = swap_accept_test(u, swap_log_prob(bj, bk, car_l, lk));
         const int ik = base + j + 1;
-        if (t == j) {
-          my_l = ok ? lk : car_l;
-          src = ok ? ik : car_i;
-          pair_acc = ok;
-        }
-        const float nl = ok ? car_l : lk;
-        const int ni = ok ? car_i : ik;
-        car_l = nl;
-        car_i = ni;
+        // Every thread of the ladder computes the same values, so the outcome for position j (which slot's vector
+        // lands there) is written to LDS by all of them, identically, and each thread picks up its own position
+        // after the loop: one ds_write per pair instead of a compare and three selects on t == j.
+        landed[base + j] = ok ? ik : car_i;
+        car_l = ok ? car_l : lk;
+        car_i = ok ? car_i : ik;
       }
-      if (t == T - 1) {
-        my_l = car_l;
-        src = car_i;
-      }
+      landed[base + T - 1] = car_i;
+      // (a wave's LDS operations complete in program order, and every wave of a wide ladder writes all positions
+      // itself before reading its own: no barrier needed)
+      src = landed[base + t];
+      my_l = s_l[src];  // log-densities travel with the states: s_l still holds the originals
+      pair_acc = (t < T - 1) && (src == base + t + 1);
     } else {
       // reference_copy: row j <- row k, row k untouched, so every pair compares the original rows j and j+1:
       // no carried state, fully parallel.
@@ -240,12 +244,12 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
   const long long chain = chain0 + cw;
   const long long rep = chain0 * T + (live ? tid : 0);  // cw * T + t == tid for a live thread
 
-  // ---- LDS (dynamic: group threads * (DP + 2) floats per group, sized by the launch: step_kernel_lds_bytes) --
+  // ---- LDS (dynamic: group threads * (DP + 3) floats per group, sized by the launch: step_kernel_lds_bytes) --
   // s_stage: one row of up to DP floats per thread; the group packs its live replicas' rows back to back (row
   // stride = dim) for the coalesced state load / store and exchanges rows through it in a swap.
-  // s_l / s_u (behind the rows): per-thread log-density and swap uniform, read back broadcast during a swap sweep.
+  // s_l / s_u / landed (behind the rows): per-thread log-density, swap uniform and swap outcome of a swap sweep.
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-  float *const s_stage = s_dyn + (wide ? 0 : (int)(threadIdx.x >> 6) * (64 * (DP + 2)));
+  float *const s_stage = s_dyn + (wide ? 0 : (int)(threadIdx.x >> 6) * (64 * (DP + kLdsExtraPerThread)));
   // group-wide ordering of LDS accesses: the group is one wave (narrow) or the workgroup (wide)
   auto sync_group = [&]() {
     if (wide) {
@@ -353,7 +357,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       const int slot = wide ? tid_s : (tid_s & 63);  // this thread's slot in s_l / s_u and its row in s_stage
       const int t = opaque_vgpr((int)c3_base) & 0xff;  // the temperature index, as the Philox counter holds it
       const int group_threads = wide ? ((T + 63) & ~63) : 64;
-      float *const rows = s_dyn + (wide ? 0 : (tid_s >> 6) * (64 * (DP + 2)));
+      float *const rows = s_dyn + (wide ? 0 : (tid_s >> 6) * (64 * (DP + kLdsExtraPerThread)));
       float *const s_l = rows + group_threads * DP;
       float *const s_u = s_l + group_threads;
       const int base = live ? slot - t : 0;            // slot of temperature 0 of this thread's ladder
@@ -373,7 +377,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       s_u[slot] = us;
       sync_group();
       swap_decide(T, t, base, slot, a.swap_mode, a.swap_order, (ev_par0 + swap_in_call) & 1, a.beta, beta_t, us, s_l, s_u,
-                  my_l, src, pair_acc);
+                  reinterpret_cast<int *>(s_u + group_threads), my_l, src, pair_acc);
       if (pair_acc) {
         ++n_swap_acc;
         last_event = swap_in_call;
@@ -433,7 +437,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     const int T2 = fresh_dim<false>(T), D2 = EXACT ? DP : fresh_dim<false>(D0), cpw2 = fresh_dim<false>(cpw);
     const bool wide2 = T2 > 64;
     const int tid2 = wide2 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
-    float *const rows2 = s_dyn + (wide2 ? 0 : (int)(threadIdx.x >> 6) * (64 * (DP + 2)));
+    float *const rows2 = s_dyn + (wide2 ? 0 : (int)(threadIdx.x >> 6) * (64 * (DP + kLdsExtraPerThread)));
     const long long c0 = (wide2 ? (long long)blockIdx.x : (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * cpw2;
     const long long live_chains = (a.n_chains - c0 < cpw2) ? (a.n_chains - c0) : cpw2;
     const int stage_total = (int)live_chains * T2 * D2;
