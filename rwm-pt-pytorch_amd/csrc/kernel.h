@@ -26,8 +26,10 @@ namespace ptrwm {
 constexpr int kBlockThreads = PTRWM_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 // dynamic LDS bytes of a step-kernel workgroup of `threads` threads with register width dp: one row of dp floats
-// per thread plus its log-density, swap-uniform and swap-outcome slots
-constexpr int kLdsExtraPerThread = 3;
+// per thread plus its log-density, swap-uniform and swap-outcome slots and three words that live for the whole
+// launch but are touched only in swap events and the epilogue (parked in LDS to keep them out of the VGPR budget
+// of the MH part: without that the compiler spilled five VGPRs to scratch, 42 MB of HBM traffic per launch)
+constexpr int kLdsExtraPerThread = 6;  // s_l, s_u, landed (swap-event scratch); c3, swap count, last event (whole launch)
 constexpr unsigned step_kernel_lds_bytes(int threads, int dp) {
   return (unsigned)(threads * (dp + kLdsExtraPerThread)) * 4u;
 }
@@ -288,8 +290,16 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
   rc.k1 = a.k1;
   const uint32_t c3_base = (uint32_t)t | ((uint32_t)(gchain >> 32) << 12);
 
-  unsigned n_acc = 0, n_swap_acc = 0;
-  int last_event = -1;  // index within this launch of the last swap event whose pair (t, t+1) accepted
+  unsigned n_acc = 0;
+  {
+    // parked in LDS (see step_kernel_lds_bytes): the Philox word with the temperature index, the number of accepted
+    // swaps of pair (t, t+1) and the index within this launch of the last swap event in which it accepted
+    const int gt = wide ? ((T + 63) & ~63) : 64;
+    int *const park = reinterpret_cast<int *>(s_stage + gt * (DP + 3)) + tid;
+    park[0] = (int)c3_base;
+    park[gt] = 0;
+    park[2 * gt] = -1;
+  }
   double sq = 0.0;
 
   const bool ext = FULL && a.full.ext_prop != nullptr;
@@ -355,11 +365,13 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       // register (or a scratch slot) across the MH part of the step.
       const int tid_s = opaque_vgpr((int)threadIdx.x);
       const int slot = wide ? tid_s : (tid_s & 63);  // this thread's slot in s_l / s_u and its row in s_stage
-      const int t = opaque_vgpr((int)c3_base) & 0xff;  // the temperature index, as the Philox counter holds it
       const int group_threads = wide ? ((T + 63) & ~63) : 64;
       float *const rows = s_dyn + (wide ? 0 : (tid_s >> 6) * (64 * (DP + kLdsExtraPerThread)));
       float *const s_l = rows + group_threads * DP;
       float *const s_u = s_l + group_threads;
+      int *const park = reinterpret_cast<int *>(rows + group_threads * (DP + 3)) + slot;
+      const uint32_t c3_s = (uint32_t)park[0];
+      const int t = (int)(c3_s & 0xffu);  // the temperature index, as the Philox counter holds it
       const int base = live ? slot - t : 0;            // slot of temperature 0 of this thread's ladder
       // src = slot whose post-MH vector ends up at this thread's temperature
       int src = slot;
@@ -369,7 +381,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       if (ext) {
         us = (t < T - 1) ? a.full.ext_swap_u[((long long)swap_in_call * a.n_chains + chain) * (T - 1) + t] : 2.0f;
       } else {
-        const u32x4 r = philox4x32_10(rc.c0hi, rc.c1, rc.c2, c3_base | (kStreamSwap << 8), rc.k0, rc.k1);
+        const u32x4 r = philox4x32_10(rc.c0hi, rc.c1, rc.c2, c3_s | (kStreamSwap << 8), rc.k0, rc.k1);
         us = u01(r.x);
       }
       // publish this thread's log-density and swap uniform; the sweep reads them back with broadcast ds_reads
@@ -379,8 +391,8 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       swap_decide(T, t, base, slot, a.swap_mode, a.swap_order, (ev_par0 + swap_in_call) & 1, a.beta, beta_t, us, s_l, s_u,
                   reinterpret_cast<int *>(s_u + group_threads), my_l, src, pair_acc);
       if (pair_acc) {
-        ++n_swap_acc;
-        last_event = swap_in_call;
+        park[group_threads] += 1;
+        park[2 * group_threads] = swap_in_call;
       }
       // commit MH move and swap in one pass: every thread publishes its post-MH vector as its slab row, then
       // fetches the row of slot `src` (rows exchanged through LDS: 2 LDS ops per dimension, no HBM)
@@ -438,7 +450,8 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     const bool wide2 = T2 > 64;
     const int tid2 = wide2 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
     float *const rows2 = s_dyn + (wide2 ? 0 : (int)(threadIdx.x >> 6) * (64 * (DP + kLdsExtraPerThread)));
-    const long long c0 = (wide2 ? (long long)blockIdx.x : (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * cpw2;
+    const long long bid = (long long)fresh_dim<false>((int)blockIdx.x);  // re-read here, not carried in a VGPR
+    const long long c0 = (wide2 ? bid : bid * kWavesPerBlock + (threadIdx.x >> 6)) * cpw2;
     const long long live_chains = (a.n_chains - c0 < cpw2) ? (a.n_chains - c0) : cpw2;
     const int stage_total = (int)live_chains * T2 * D2;
     const long long stage_g0 = c0 * T2 * (long long)D2;
@@ -459,7 +472,12 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     const int tid_o = opaque_vgpr((int)threadIdx.x);
     const int T_o = fresh_dim<false>(T);
     const long long rep = c0_out * T_o + (T_o > 64 ? tid_o : (tid_o & 63));  // live: replica index in group == tid
-    const int t = opaque_vgpr((int)c3_base) & 0xff;
+    const int gt_o = T_o > 64 ? ((T_o + 63) & ~63) : 64;
+    const int *const park = reinterpret_cast<const int *>(s_dyn + (T_o > 64 ? 0 : (tid_o >> 6) * (64 * (DP + kLdsExtraPerThread)))
+                                                          + gt_o * (DP + 3)) + (T_o > 64 ? tid_o : (tid_o & 63));
+    const int t = park[0] & 0xff;
+    const unsigned n_swap_acc = (unsigned)park[gt_o];
+    const int last_event = park[2 * gt_o];
     a.logp[rep] = lp;
     if (a.n_accept != nullptr) a.n_accept[rep] += (long long)n_acc;
     if (a.sq_jump != nullptr) a.sq_jump[rep] += sq;
