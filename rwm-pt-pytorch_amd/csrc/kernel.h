@@ -212,12 +212,15 @@ __device__ __forceinline__ int fresh_dim(int d0) {
 #ifndef PTRWM_WAVES_SMALL  // tuning knobs (profiles/r01_bench_variants.txt: 4 beats 3, 5 and 6 at dim 30)
 #define PTRWM_WAVES_SMALL 4
 #endif
+#ifndef PTRWM_WAVES_40
+#define PTRWM_WAVES_40 3
+#endif
 #ifndef PTRWM_WAVES_MID
 #define PTRWM_WAVES_MID 2
 #endif
 // (Width 40 at 4 waves/SIMD spilled ~75 VGPRs; 3 waves/SIMD = 168 VGPRs holds it.)
 constexpr int min_waves_per_simd(int dp) {
-  return dp <= 36 ? PTRWM_WAVES_SMALL : (dp <= 44 ? 3 : (dp <= 64 ? PTRWM_WAVES_MID : 1));
+  return dp <= 36 ? PTRWM_WAVES_SMALL : (dp <= 44 ? PTRWM_WAVES_40 : (dp <= 64 ? PTRWM_WAVES_MID : 1));
 }
 
 // DP    compile-time width of the per-thread register arrays (>= dim)

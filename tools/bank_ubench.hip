@@ -46,6 +46,26 @@ __global__ void __launch_bounds__(256) k(float *out, int iters) {
 }
 
 template <int V>
+void run_occ(const char *name, float *d, int waves_per_simd) {
+  // blocks of 4 waves (one per SIMD); waves_per_simd blocks per CU: issue interval of a wave vs latency hiding
+  const int iters = 4000, blocks = 256 * waves_per_simd;
+  hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), 0, 0, d, 10);
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), 0, 0, d, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double insts_per_simd = (double)waves_per_simd * iters * 32;
+  printf("%-30s %2d waves/SIMD: %.2f cycles per wave-instruction per SIMD (%.2f per wave)\n", name, waves_per_simd,
+         ms * 1e-3 * 2.4e9 / insts_per_simd, ms * 1e-3 * 2.4e9 / (iters * 32.0));
+}
+
+template <int V>
 void run(const char *name, float *d) {
   const int iters = 2000, blocks = 256 * 4 * 4;  // 4 blocks of 4 waves per CU: 4 waves per SIMD
   hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), 0, 0, d, 10);
@@ -79,5 +99,8 @@ int main() {
   run<9>("max3 1 bank", d);
   run<10>("fmamk 2 banks", d);
   run<11>("fmamk 1 bank", d);
+  for (int w : {1, 2, 3, 4, 6, 8}) run_occ<0>("independent fma", d, w);
+  for (int w : {1, 2, 3, 4, 6, 8}) run_occ<7>("dependent fma chain", d, w);
+  for (int w : {1, 2, 4, 8}) run_occ<3>("independent mul (2 src)", d, w);
   return 0;
 }
