@@ -12,6 +12,7 @@ What is captured:
   rwm_*.npz        full RandomWalkMH_GPU_Optimized trajectories + the random tensors they consumed
   pt_*.npz         full ParallelTemperingRWM_GPU_Optimized trajectories + their random tensors
   pt_sweep.npz     `_attempt_all_swaps()` called on its own on a batch of ladders
+  superfunnel.npz  SuperFunnelTorch.log_density on ragged synthetic data
   numpy_baseline.json / numpy_*.npz   the NumPy CPU samplers (algorithms/rwm.py, pt_rwm.py)
 """
 import contextlib
@@ -337,6 +338,27 @@ def gen_sweep(T):
          pt_esjd=np.asarray(esjd, np.float64), target_key=np.array("rc15_d30"))
 
 
+def gen_superfunnel():
+    """SuperFunnelTorch.log_density (funnel_torch.py:193-291) on ragged synthetic data at random states, some with a
+    non-positive tau (log density -inf)."""
+    print("SuperFunnel log-density fixture")
+    J, K, n_j = 3, 2, [5, 7, 4]
+    rng = np.random.default_rng(99)
+    X = [rng.normal(size=(n, K)).astype(np.float32) for n in n_j]
+    Y = [(rng.random(n) < 0.5).astype(np.float32) for n in n_j]
+    t = quiet(ref_tgt.SuperFunnelTorch, J, K, [torch.from_numpy(x) for x in X], [torch.from_numpy(y) for y in Y],
+              device="cpu")
+    dim = J + J * K + 1 + K + 2
+    th = rng.normal(0.0, 1.5, size=(40, dim)).astype(np.float32)
+    th[:, -2:] = np.abs(th[:, -2:]) + 0.05
+    th[3, -1] = -0.3
+    th[7, -2] = 0.0
+    th[11, -2:] = 1e-10
+    ref = t.log_density(torch.from_numpy(th)).numpy()
+    save("superfunnel.npz", J=np.int64(J), K=np.int64(K), n_j=np.asarray(n_j, np.int64), X=np.concatenate(X, 0),
+         Y=np.concatenate(Y, 0), theta=th, log_density=ref, target_name=np.array(t.get_name()), dim=np.int64(t.dim))
+
+
 # ------------------------------------------------------------------------------------------------
 # NumPy CPU samplers (BASELINE config 1 and a small PT run)
 # ------------------------------------------------------------------------------------------------
@@ -393,7 +415,7 @@ def gen_numpy():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["logdensity", "proposals", "rwm", "pt", "sweep", "numpy"]
+    which = sys.argv[1:] or ["logdensity", "proposals", "rwm", "pt", "sweep", "superfunnel", "numpy"]
     T = make_targets()
     if "logdensity" in which:
         gen_logdensity(T)
@@ -405,5 +427,7 @@ if __name__ == "__main__":
         gen_pt(T)
     if "sweep" in which:
         gen_sweep(T)
+    if "superfunnel" in which:
+        gen_superfunnel()
     if "numpy" in which:
         gen_numpy()

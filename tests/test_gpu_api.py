@@ -538,3 +538,26 @@ def test_bench_emits_the_contract_line(device):
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     units = d["config"]["ladders_per_gpu"] * d["config"]["temps"] * d["config"]["mh_steps_per_launch"]
     assert abs(d["value"] - units * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-6
+
+
+def test_superfunnel_runs_through_split_steps(device):
+    """The reference's remaining torch target: PT on SuperFunnelTorch (no fused kernel) through the drop-in class."""
+    from target_distributions import SuperFunnelTorch
+
+    f = H.load("superfunnel.npz")
+    cuts = np.cumsum(f["n_j"])[:-1]
+    X = [torch.from_numpy(x) for x in np.split(f["X"], cuts)]
+    Y = [torch.from_numpy(y) for y in np.split(f["Y"], cuts)]
+    t = SuperFunnelTorch(int(f["J"]), int(f["K"]), X, Y, device=device)
+    got = t.log_density(torch.from_numpy(f["theta"]).to(device)).cpu().numpy()
+    fin = np.isfinite(f["log_density"])
+    assert np.allclose(got[fin], f["log_density"][fin], rtol=2e-6, atol=1e-4)
+    torch.manual_seed(4)
+    with pytest.warns(UserWarning, match="split steps"):
+        pt = ParallelTemperingRWM_GPU_Optimized(t.dim, 0.05, t, beta_ladder=[1.0, 0.6, 0.3], swap_every=4, burn_in=50,
+                                                device=device, num_replicas=256, seed=8, trace="cold")
+        pt._initial_state = np.concatenate([np.zeros(t.dim - 2), [1.0, 1.0]])  # taus must start positive
+        cold = pt.generate_samples(150)
+    assert cold.shape == (150, t.dim) and torch.isfinite(cold).all()
+    assert torch.isfinite(pt._run.logp).all() and (pt._run.state[..., -2:] > 1e-9).all()
+    assert 0.05 < float(pt.mh_acceptance_rates()[0]) < 0.95 and pt.num_swap_attempts > 0

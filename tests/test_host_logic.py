@@ -270,3 +270,31 @@ def test_summary_pack_roundtrip():
     np.testing.assert_allclose(out["acceptance_rate"].numpy(), s["accept_count"].numpy() / 480)
     np.testing.assert_allclose(out["esjd"].numpy(), s["sq_jump_sum"].numpy() / 480)
     assert out["swap_acceptance_rate"] == pytest.approx(26 / 96)
+
+
+def test_superfunnel_density_matches_the_reference():
+    """SuperFunnelTorch (hierarchical logistic regression, ragged data): the batched formulation reproduces the
+    reference's log_density (tests/golden/superfunnel.npz, funnel_torch.py:193-291), -inf cases included.  It has no
+    fused kernel (engine_target raises): the samplers run it in split steps."""
+    import numpy as np
+    import torch
+
+    import helpers as H
+    from target_distributions import SuperFunnelTorch
+
+    f = H.load("superfunnel.npz")
+    cuts = np.cumsum(f["n_j"])[:-1]
+    X = [torch.from_numpy(x) for x in np.split(f["X"], cuts)]
+    Y = [torch.from_numpy(y) for y in np.split(f["Y"], cuts)]
+    t = SuperFunnelTorch(int(f["J"]), int(f["K"]), X, Y, device="cpu")
+    assert t.get_name() == str(f["target_name"]) and t.dim == int(f["dim"])
+    got = t.log_density(torch.from_numpy(f["theta"])).numpy()
+    ref = f["log_density"]
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), fin) and (~fin).sum() == 3
+    assert np.allclose(got[fin], ref[fin], rtol=2e-6, atol=1e-4)
+    assert float(t.log_density(torch.from_numpy(f["theta"][0]))) == pytest.approx(float(ref[0]), rel=2e-6)
+    with pytest.raises(NotImplementedError):
+        t.engine_target()
+    with pytest.raises(ValueError):
+        SuperFunnelTorch(2, 2, X, Y)
