@@ -298,3 +298,44 @@ def test_superfunnel_density_matches_the_reference():
         t.engine_target()
     with pytest.raises(ValueError):
         SuperFunnelTorch(2, 2, X, Y)
+
+
+def test_driver_target_factory_calls_construct():
+    """Every constructor call the reference's GPU experiment drivers make (experiment_pt_GPU.py:20-140,
+    experiment_RWM_GPU.py: get_target_distribution, use_torch=True) works against this package with the same keyword
+    arguments - a driver switched to this package by PYTHONPATH finds every torch target it asks for."""
+    import torch
+
+    import target_distributions as TD
+
+    dim, dev = 10, torch.device("cpu")
+    centers = [[-15.0] + [0.0] * (dim - 1), [0.0] * dim, [15.0] + [0.0] * (dim - 1)]
+    made = [
+        TD.MultivariateNormalTorch(dim, device=dev),
+        TD.ScaledMultivariateNormalTorch(dim, device=dev),
+        TD.RoughCarpetDistributionTorch(dim, scaling=False, device=dev, mode_centers=[-15.0, 0.0, 15.0],
+                                        mode_weights=[0.5, 0.3, 0.2]),
+        TD.RoughCarpetDistributionTorch(dim, scaling=True, device=dev, mode_centers=[-15.0, 0.0, 15.0],
+                                        mode_weights=[0.5, 0.3, 0.2]),
+        TD.ThreeMixtureDistributionTorch(dim, scaling=False, device=dev, mode_centers=centers, mode_weights=[1 / 3] * 3),
+        TD.ThreeMixtureDistributionTorch(dim, scaling=True, device=dev, mode_centers=centers, mode_weights=[1 / 3] * 3),
+        TD.HypercubeTorch(dim, left_boundary=-1, right_boundary=1, device=dev),
+        TD.IIDGammaTorch(dim, shape=2, scale=3, device=dev),
+        TD.IIDBetaTorch(dim, alpha=2, beta=3, device=dev),
+        TD.FullRosenbrockTorch(dim, a_coeff=1.0 / 20.0, b_coeff=100.0 / 20.0, mu=1.0, device=dev),
+        TD.EvenRosenbrockTorch(dim, a_coeff=1.0 / 20.0, b_coeff=100.0 / 20.0, mu=1.0, device=dev),
+        TD.HybridRosenbrockTorch(n1=3, n2=5, a_coeff=1.0 / 20.0, b_coeff=100.0 / 20.0, mu=1.0, device=dev),
+        TD.NealFunnelTorch(dim, mu_v=0.0, sigma_v_sq=9.0, mu_z=0.0, device=dev),
+    ]
+    J, K = 5, 3
+    torch.manual_seed(42)
+    X = [torch.randn(20, K) for _ in range(J)]
+    Y = [(torch.rand(20) < 0.5).float() for _ in range(J)]
+    made.append(TD.SuperFunnelTorch(J, K, X, Y, prior_hypermean_std=10.0, prior_tau_scale=2.5, device=dev))
+    assert made[-1].dim == J + J * K + 1 + K + 1 + 1 and made[11].dim == 1 + 5 * (3 - 1)
+    for t in made:
+        assert isinstance(t.get_name(), str) and t.dim >= 1
+        # everything but the dense Gaussian / SuperFunnel describes itself to the fused kernel
+    fused = [t for t in made if t is not made[-1]]
+    for t in fused:
+        assert t.engine_target().dim == t.dim
