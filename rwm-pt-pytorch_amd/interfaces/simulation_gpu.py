@@ -113,6 +113,32 @@ class MCMCSimulation_GPU:
         self._require_run()
         return self.algorithm.pt_esjd
 
+    def benchmark_performance(self, num_samples_list=(1000, 5000, 10000, 50000), compare_cpu=False):
+        """Wall-clock of `generate_samples` at several run lengths (reference simulation_gpu.py:252-311; same result
+        keys).  There is no CPU sampler behind this harness, so the cpu_* / speedup entries stay None."""
+        if compare_cpu:
+            import warnings
+
+            warnings.warn("compare_cpu=True ignored: this engine has no CPU path to compare against")
+        sizes = list(num_samples_list)
+        results = {"sample_sizes": sizes, "gpu_times": [], "gpu_samples_per_sec": [], "cpu_times": None,
+                   "cpu_samples_per_sec": None, "speedup": None}
+        original = self.num_iterations
+        try:
+            for n in sizes:
+                self.reset()
+                self.num_iterations = n
+                t0 = time.time()
+                self.generate_samples(progress_bar=False, as_list=False)
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                dt = max(time.time() - t0, 1e-12)
+                results["gpu_times"].append(dt)
+                results["gpu_samples_per_sec"].append(n / dt)
+        finally:
+            self.num_iterations = original
+        return results
+
     def _create_proposal_distribution(self, dim: int, beta: float, proposal_config: dict, device: torch.device,
                                       dtype: torch.dtype, use_efficient_rng: bool = True) -> ProposalDistribution:
         """{'name': 'Normal'|'Laplace'|'UniformRadius', 'params': {...}} -> proposal object."""

@@ -183,6 +183,16 @@ def test_simulation_harness_with_each_proposal(device, name, params):
     assert chain2 == chain
 
 
+def test_harness_benchmark_helper(device):
+    """MCMCSimulation_GPU.benchmark_performance (reference :252-311): same result keys, GPU timings only."""
+    target = RoughCarpetDistributionTorch(10, device=device)
+    sim = MCMCSimulation_GPU(dim=10, sigma=0.5, num_iterations=100, algorithm=RandomWalkMH_GPU_Optimized,
+                             target_dist=target, seed=1, device=device, burn_in=10)
+    res = sim.benchmark_performance(num_samples_list=[200, 400])
+    assert res["sample_sizes"] == [200, 400] and len(res["gpu_times"]) == 2 and res["cpu_times"] is None
+    assert all(v > 0 for v in res["gpu_samples_per_sec"]) and sim.num_iterations == 100
+
+
 def test_pt_class_api_and_statistics(device):
     """tests/test_pt_gpu_optimizations.py:91-93, :296-297: swap attempts, swap rate, cold-chain moments."""
     torch.manual_seed(1)
