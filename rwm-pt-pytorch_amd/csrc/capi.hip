@@ -5,20 +5,33 @@
 
 namespace ptrwm {
 
-static const TargetVariants *target_variants(int kind, bool two_term = false) {
-  switch (kind) {
-    case PTRWM_TARGET_ROUGH_CARPET: return two_term ? &rough_carpet2_variants() : &rough_carpet_variants();
-    case PTRWM_TARGET_THREE_MIXTURE: return &three_mixture_variants();
-    case PTRWM_TARGET_FULL_ROSENBROCK: return &full_rosenbrock_variants();
-    case PTRWM_TARGET_EVEN_ROSENBROCK: return &even_rosenbrock_variants();
-    case PTRWM_TARGET_HYBRID_ROSENBROCK: return &hybrid_rosenbrock_variants();
-    case PTRWM_TARGET_IID_GAMMA: return &iid_gamma_variants();
-    case PTRWM_TARGET_IID_BETA: return &iid_beta_variants();
-    case PTRWM_TARGET_DIAG_GAUSSIAN: return &diag_gaussian_variants();
-    case PTRWM_TARGET_HYPERCUBE: return &hypercube_variants();
-    case PTRWM_TARGET_NEAL_FUNNEL: return &neal_funnel_variants();
-    default: return nullptr;
+struct VariantPair {
+  const TargetVariants *narrow, *wide;  // each holds null entries for the other group's widths (variants.h)
+  RunLaunchFn run(int proposal, int dpi) const {
+    const RunLaunchFn f = narrow->run[proposal][dpi];
+    return f != nullptr ? f : wide->run[proposal][dpi];
   }
+  LogpLaunchFn logp(int dpi) const {
+    const LogpLaunchFn f = narrow->logp[dpi];
+    return f != nullptr ? f : wide->logp[dpi];
+  }
+};
+
+static VariantPair target_variants(int kind, bool two_term = false) {
+#define PTRWM_PAIR(SYMBOL) VariantPair{&SYMBOL##_narrow(), &SYMBOL##_wide()}
+  switch (kind) {
+    case PTRWM_TARGET_ROUGH_CARPET: return two_term ? PTRWM_PAIR(rough_carpet2_variants) : PTRWM_PAIR(rough_carpet_variants);
+    case PTRWM_TARGET_THREE_MIXTURE: return PTRWM_PAIR(three_mixture_variants);
+    case PTRWM_TARGET_FULL_ROSENBROCK: return PTRWM_PAIR(full_rosenbrock_variants);
+    case PTRWM_TARGET_EVEN_ROSENBROCK: return PTRWM_PAIR(even_rosenbrock_variants);
+    case PTRWM_TARGET_HYBRID_ROSENBROCK: return PTRWM_PAIR(hybrid_rosenbrock_variants);
+    case PTRWM_TARGET_IID_GAMMA: return PTRWM_PAIR(iid_gamma_variants);
+    case PTRWM_TARGET_IID_BETA: return PTRWM_PAIR(iid_beta_variants);
+    case PTRWM_TARGET_DIAG_GAUSSIAN: return PTRWM_PAIR(diag_gaussian_variants);
+    case PTRWM_TARGET_HYPERCUBE: return PTRWM_PAIR(hypercube_variants);
+    default: return PTRWM_PAIR(neal_funnel_variants);
+  }
+#undef PTRWM_PAIR
 }
 
 static int check_target(const ptrwm_target_desc *t) {
@@ -337,7 +350,7 @@ int32_t ptrwm_has_variant(int32_t target_kind, int32_t proposal_kind, int32_t di
   if (proposal_kind < 0 || proposal_kind >= PTRWM_PROPOSAL_COUNT) return 0;
   const int dpi = width_index_for_dim(dim);
   if (dim < 1 || dpi < 0) return 0;
-  return target_variants(target_kind)->run[proposal_kind][dpi] != nullptr ? 1 : 0;
+  return target_variants(target_kind).run(proposal_kind, dpi) != nullptr ? 1 : 0;
 }
 
 int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *proposal, const ptrwm_run_args *args,
@@ -365,7 +378,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   const int dpi = width_index_for_dim(target->dim);
   if (dpi < 0) return PTRWM_E_DIM;
   const bool two_term = target->kind == PTRWM_TARGET_ROUGH_CARPET && rough_carpet_two_term(target->p);
-  const RunLaunchFn fn = target_variants(target->kind, two_term)->run[proposal->kind][dpi];
+  const RunLaunchFn fn = target_variants(target->kind, two_term).run(proposal->kind, dpi);
   if (fn == nullptr) return PTRWM_E_NOVARIANT;
 
   const long long se = args->swap_every;
@@ -553,7 +566,7 @@ int32_t ptrwm_logdensity(const ptrwm_target_desc *target, const float *x, float 
   if (x == nullptr || out == nullptr) return PTRWM_E_NULL;
   const int dpi = width_index_for_dim(target->dim);
   if (dpi < 0) return PTRWM_E_DIM;
-  const LogpLaunchFn fn = target_variants(target->kind)->logp[dpi];
+  const LogpLaunchFn fn = target_variants(target->kind).logp(dpi);
   if (fn == nullptr) return PTRWM_E_NOVARIANT;
   const hipError_t err = fn(x, out, n, target->dim, make_tparams(target), (hipStream_t)stream);
   return err == hipSuccess ? PTRWM_OK : PTRWM_E_LAUNCH;

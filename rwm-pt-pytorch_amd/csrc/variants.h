@@ -12,10 +12,16 @@ namespace ptrwm {
 // predicates: at widths <= 32 they measure within a few per cent of an exact kernel (dim 29/31/32 vs 30), at
 // widths 40-64 (2 waves/SIMD) about 25 % slower per dimension (dim 41/49 vs 50); a dim that matters can be added
 // to the exact list at build time (profiles/r01_bench_variants.txt).  X(width, exact)
-#define PTRWM_WIDTHS(X) \
-  X(2, true) X(3, true) X(4, true) X(5, true) X(10, true) X(20, true) X(30, true) X(50, true) X(100, true) \
-  X(8, false) X(16, false) X(24, false) X(32, false) X(40, false) X(48, false) X(56, false) X(64, false) \
-  X(80, false) X(104, false)
+// Two groups, compiled into separate objects from the same source (csrc/Makefile): the NARROW widths (<= 64, at most
+// 232 VGPRs) are built with the max-ILP scheduling strategy, the WIDE ones (80, 100, 104: more than 256 VGPRs, i.e.
+// AGPR spilling next to the SGPR-spill lanes) with the compiler's default - under max-ILP hipcc miscompiled wide
+// fixture kernels (garbage SGPR reloads: a wild ext_u address in RoughCarpet2/UniformRadius width 80, found by
+// tools/fuzz_vs_oracle.py and pinned down with rocgdb).
+#define PTRWM_WIDTHS_NARROW(X) \
+  X(2, true) X(3, true) X(4, true) X(5, true) X(10, true) X(20, true) X(30, true) X(50, true) \
+  X(8, false) X(16, false) X(24, false) X(32, false) X(40, false) X(48, false) X(56, false) X(64, false)
+#define PTRWM_WIDTHS_WIDE(X) X(100, true) X(80, false) X(104, false)
+#define PTRWM_WIDTHS(X) PTRWM_WIDTHS_NARROW(X) PTRWM_WIDTHS_WIDE(X)
 
 struct WidthInfo {
   int dp;
@@ -86,27 +92,39 @@ hipError_t launch_logp(const float *x, float *out, long long n, int D, const TPa
 #define PTRWM_X_RUN_L(W, E) launch_run<TGT<W>, LaplaceProposal<W>, W, E>,
 #define PTRWM_X_RUN_U(W, E) launch_run<TGT<W>, UniformRadiusProposal<W>, W, E>,
 #define PTRWM_X_LOGP(W, E) launch_logp<TGT<W>, W>,
+#define PTRWM_X_NULL(W, E) nullptr,
+#ifdef PTRWM_PART_WIDE
+#define PTRWM_PART_SUFFIX(SYMBOL) SYMBOL##_wide
+#define PTRWM_PART_ROW(X) PTRWM_WIDTHS_NARROW(PTRWM_X_NULL) PTRWM_WIDTHS_WIDE(X)
+#else
+#define PTRWM_PART_SUFFIX(SYMBOL) SYMBOL##_narrow
+#define PTRWM_PART_ROW(X) PTRWM_WIDTHS_NARROW(X) PTRWM_WIDTHS_WIDE(PTRWM_X_NULL)
+#endif
+// Each object defines SYMBOL_narrow() or SYMBOL_wide(): a full-size table with null entries for the other group.
 #define PTRWM_DEFINE_TARGET_VARIANTS(SYMBOL, TARGET)                                   \
   template <int W>                                                                     \
   using TGT = TARGET<W>;                                                               \
-  const TargetVariants &SYMBOL() {                                                     \
-    static const TargetVariants v = {{{PTRWM_WIDTHS(PTRWM_X_RUN_N)},                   \
-                                      {PTRWM_WIDTHS(PTRWM_X_RUN_L)},                   \
-                                      {PTRWM_WIDTHS(PTRWM_X_RUN_U)}},                  \
-                                     {PTRWM_WIDTHS(PTRWM_X_LOGP)}};                    \
+  const TargetVariants &PTRWM_PART_SUFFIX(SYMBOL)() {                                  \
+    static const TargetVariants v = {{{PTRWM_PART_ROW(PTRWM_X_RUN_N)},                 \
+                                      {PTRWM_PART_ROW(PTRWM_X_RUN_L)},                 \
+                                      {PTRWM_PART_ROW(PTRWM_X_RUN_U)}},                \
+                                     {PTRWM_PART_ROW(PTRWM_X_LOGP)}};                  \
     return v;                                                                          \
   }
 
-const TargetVariants &rough_carpet_variants();
-const TargetVariants &rough_carpet2_variants();  // two-term specialisation, see targets.h
-const TargetVariants &three_mixture_variants();
-const TargetVariants &full_rosenbrock_variants();
-const TargetVariants &even_rosenbrock_variants();
-const TargetVariants &hybrid_rosenbrock_variants();
-const TargetVariants &iid_gamma_variants();
-const TargetVariants &iid_beta_variants();
-const TargetVariants &diag_gaussian_variants();
-const TargetVariants &hypercube_variants();
-const TargetVariants &neal_funnel_variants();
+#define PTRWM_DECLARE_TARGET_VARIANTS(SYMBOL) \
+  const TargetVariants &SYMBOL##_narrow();    \
+  const TargetVariants &SYMBOL##_wide();
+PTRWM_DECLARE_TARGET_VARIANTS(rough_carpet_variants)
+PTRWM_DECLARE_TARGET_VARIANTS(rough_carpet2_variants)  // two-term specialisation, see targets.h
+PTRWM_DECLARE_TARGET_VARIANTS(three_mixture_variants)
+PTRWM_DECLARE_TARGET_VARIANTS(full_rosenbrock_variants)
+PTRWM_DECLARE_TARGET_VARIANTS(even_rosenbrock_variants)
+PTRWM_DECLARE_TARGET_VARIANTS(hybrid_rosenbrock_variants)
+PTRWM_DECLARE_TARGET_VARIANTS(iid_gamma_variants)
+PTRWM_DECLARE_TARGET_VARIANTS(iid_beta_variants)
+PTRWM_DECLARE_TARGET_VARIANTS(diag_gaussian_variants)
+PTRWM_DECLARE_TARGET_VARIANTS(hypercube_variants)
+PTRWM_DECLARE_TARGET_VARIANTS(neal_funnel_variants)
 
 }  // namespace ptrwm

@@ -719,3 +719,29 @@ def test_wide_ladder_with_large_dim_vs_oracle(device, T, dim):
     got2 = gpu_run(spec, prop, device, state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=1, swap_every=2, seed=5)
     chk = O.logdensity(spec.oracle(), got2["state"].reshape(-1, dim), "f64").reshape(Cn, T)
     assert np.allclose(got2["logp"], chk, rtol=1e-5, atol=1e-3)
+
+
+def test_every_compiled_variant_against_the_oracle(device):
+    """tools/check_all_variants.py: all 11 target kernels x 3 proposals x 19 register widths x {fixture, production}
+    (1 254 kernels), one child process per (target, proposal) so that a GPU fault is reported instead of ending the
+    test run.  This is the guard that would have caught the width-80 miscompile under the max-ILP scheduler."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_all_variants.py")], capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "FAILED pairs: none" in r.stdout
+
+
+def test_randomised_configurations_against_the_oracle(device):
+    """tools/fuzz_vs_oracle.py, 80 random (target, dim, ladder, proposal, swap mode/order/period, burn-in) cases."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_vs_oracle.py"), "80", "7"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
+    assert "80 cases agree" in r.stdout
