@@ -8,6 +8,7 @@ Tolerances (stated once):
   * accept decisions: can only differ where |u - exp(r)| is inside that error; checked one step at a time
     ("teacher forced") so one flip cannot cascade, agreement >= 99.9 % required
 """
+import os
 import zlib
 
 import numpy as np
