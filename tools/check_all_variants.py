@@ -118,6 +118,15 @@ def one_pair(tk, pk):
         fin = np.isfinite(own)
         ok_prod = np.array_equal(np.isfinite(got_lp), fin) and np.allclose(got_lp[fin], own[fin], rtol=2e-5, atol=2e-3)
         ok_prod &= abs(int(nacc.sum()) - int(w2["n_accept"].sum())) <= max(4, 0.1 * int(w2["n_accept"].sum()))
+        # ... and the fixture variant of the same kernel, run on the same Philox stream with a trace attached, must
+        # reproduce the production variant bit for bit (the two are separate compilations of one template)
+        s_f, l_f = dt(st), dt(lp)
+        nacc_f = torch.zeros(Cn, T, dtype=torch.int64, device=dev)
+        tr = torch.zeros(40, Cn, T, dim, device=dev)
+        E.run(spec.engine(dev), prop.engine(dev), state=s_f, logp=l_f, beta=dt(beta), step0=3, n_steps=40, burn_in=0,
+              swap_every=se, seed=77 + dim, chain_offset=2, n_accept=nacc_f, trace=tr)
+        torch.cuda.synchronize()
+        ok_prod &= torch.equal(s_f, s_d) and torch.equal(l_f, l_d) and torch.equal(nacc_f, nacc) and torch.equal(tr[-1], s_d)
         if not (ok_full and ok_prod):
             bad += 1
             print(f"  MISMATCH target {tk} proposal {pname} dim {dim}: fixture ok={ok_full} (first flip {first}) production ok={ok_prod}", flush=True)
