@@ -5,6 +5,11 @@
 // register width >= dim); every loop is fully unrolled so all indexing is static
 // and the per-dimension parameter vectors are wave-uniform scalar loads.
 #pragma once
+// Evaluation functions with an `a * b +- c` pattern turn implicit FMA contraction OFF (explicit fmaf calls stay); the
+// two mixtures write their only such product, the optional per-dimension scaling, as an explicit fma instead: the same functor is compiled into the fused step kernel, the
+// stand-alone log-density kernel and both width groups, and left to the optimiser `a - b * b` became an fma in one of
+// them and two roundings in another (a 1-ulp difference between ptrwm_logdensity and the in-loop value for
+// FullRosenbrock, found by tools/fuzz_split.py).  Two roundings are also what the reference's torch expressions do.
 #include "philox.h"
 #include "../../include/ptrwm.h"
 
@@ -48,9 +53,14 @@ struct RoughCarpetT {
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
       if (d < D) {
-        float xs = y[d];
-        if constexpr (SCALED) xs *= uv0[d];
-        const float d0 = xs - m0, d1 = xs - m1, d2 = xs - m2;
+        float d0, d1, d2;
+        if constexpr (SCALED) {
+          // s x - m_k as ONE explicit fma each (what the optimiser chose when left alone, now the same in every kernel)
+          const float sc = uv0[d];
+          d0 = fmaf(y[d], sc, -m0), d1 = fmaf(y[d], sc, -m1), d2 = fmaf(y[d], sc, -m2);
+        } else {
+          d0 = y[d] - m0, d1 = y[d] - m1, d2 = y[d] - m2;
+        }
         const float a0 = fmaf(d0 * d0, nh, w0);
         const float a1 = fmaf(d1 * d1, nh, w1);
         const float a2 = fmaf(d2 * d2, nh, w2);
@@ -101,11 +111,13 @@ struct ThreeMixture {
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
       if (d < D) {
-        float xs = y[d];
-        if constexpr (SCALED) xs *= uv1[d];
-        const float e0 = xs - uv0[d];
-        const float e1 = xs - uv0[D + d];
-        const float e2 = xs - uv0[2 * D + d];
+        float e0, e1, e2;
+        if constexpr (SCALED) {
+          const float sc = uv1[d];  // s x - mu_k as one explicit fma each, the same in every kernel
+          e0 = fmaf(y[d], sc, -uv0[d]), e1 = fmaf(y[d], sc, -uv0[D + d]), e2 = fmaf(y[d], sc, -uv0[2 * D + d]);
+        } else {
+          e0 = y[d] - uv0[d], e1 = y[d] - uv0[D + d], e2 = y[d] - uv0[2 * D + d];
+        }
         q0 = fmaf(e0, e0, q0);
         q1 = fmaf(e1, e1, q1);
         q2 = fmaf(e2, e2, q2);
@@ -133,6 +145,7 @@ struct FullRosenbrock {
   static constexpr int kKind = PTRWM_TARGET_FULL_ROSENBROCK;
   template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+#pragma clang fp contract(off)
     const float a = tp.p[0], b = tp.p[1];
     float s1 = 0.0f, s2 = 0.0f;
     const const_float_ptr uv0 = uniform_vec(tp.vec0);
@@ -157,6 +170,7 @@ struct EvenRosenbrock {
   static constexpr int kKind = PTRWM_TARGET_EVEN_ROSENBROCK;
   template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+#pragma clang fp contract(off)
     const float a = tp.p[0], b = tp.p[1];
     float s1 = 0.0f, s2 = 0.0f;
     const const_float_ptr uv0 = uniform_vec(tp.vec0);
@@ -183,6 +197,7 @@ struct HybridRosenbrock {
   static constexpr int kKind = PTRWM_TARGET_HYBRID_ROSENBROCK;
   template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+#pragma clang fp contract(off)
     const float a = tp.p[0], b = tp.p[1], mu = tp.p[2];
     const float c0 = y[0] - mu;
     float acc = a * c0 * c0;
@@ -207,6 +222,7 @@ struct IIDGamma {
   static constexpr int kKind = PTRWM_TARGET_IID_GAMMA;
   template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+#pragma clang fp contract(off)
     const float km1 = (tp.p[0] - 1.0f) * kLn2;
     const float inv_theta = 1.0f / tp.p[1];
     float acc = 0.0f;
@@ -231,6 +247,7 @@ struct IIDBeta {
   static constexpr int kKind = PTRWM_TARGET_IID_BETA;
   template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+#pragma clang fp contract(off)
     const float am1 = (tp.p[0] - 1.0f) * kLn2;
     const float bm1 = (tp.p[1] - 1.0f) * kLn2;
     float acc = 0.0f;
@@ -255,6 +272,7 @@ struct DiagGaussian {
   static constexpr int kKind = PTRWM_TARGET_DIAG_GAUSSIAN;
   template <bool SCALED_FORM>
   __device__ __forceinline__ static float quad(const float (&y)[DP], int D, const TParams &tp) {
+#pragma clang fp contract(off)
     float q = 0.0f;
     const const_float_ptr uv0 = uniform_vec(tp.vec0);
     [[maybe_unused]] const const_float_ptr uv1 = SCALED_FORM ? nullptr : uniform_vec(tp.vec1);
@@ -275,6 +293,7 @@ struct DiagGaussian {
   }
   template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+#pragma clang fp contract(off)
     const float q = tp.ip[0] != 0 ? quad<true>(y, D, tp) : quad<false>(y, D, tp);
     return fmaf(-0.5f, q, tp.p[0]);
   }
@@ -286,6 +305,7 @@ struct Hypercube {
   static constexpr int kKind = PTRWM_TARGET_HYPERCUBE;
   template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+#pragma clang fp contract(off)
     const float lo = tp.p[0], hi = tp.p[1];
     bool inside = true;
 #pragma unroll
@@ -302,6 +322,7 @@ struct NealFunnel {
   static constexpr int kKind = PTRWM_TARGET_NEAL_FUNNEL;
   template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
+#pragma clang fp contract(off)
     const float mu_v = tp.p[0], s2 = tp.p[1], mu_z = tp.p[2];
     const float log_2pi = 1.8378770664093453f;
     const float v = y[0];

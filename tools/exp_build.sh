@@ -9,16 +9,23 @@ mkdir -p $OUT $OBJ
 cat > $OBJ/stubs.hip <<'EOS'
 #include "../csrc/variants.h"
 namespace ptrwm {
-#define STUB(fn) const TargetVariants &fn() { static const TargetVariants v = {}; return v; }
+#define STUB(fn) const TargetVariants &fn##_narrow() { static const TargetVariants v = {}; return v; } \
+                 const TargetVariants &fn##_wide() { static const TargetVariants v = {}; return v; }
 STUB(three_mixture_variants) STUB(full_rosenbrock_variants) STUB(even_rosenbrock_variants)
 STUB(hybrid_rosenbrock_variants) STUB(iid_gamma_variants) STUB(iid_beta_variants) STUB(diag_gaussian_variants)
 STUB(hypercube_variants) STUB(neal_funnel_variants)
 }
 EOS
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $*"
-for f in capi.hip variants_rough_carpet.hip variants_rough_carpet2.hip $OBJ/stubs.hip; do
-  /opt/rocm/bin/hipcc $FLAGS -c $f -o $OBJ/$(basename ${f%.hip}).o &
+# the flags given on the command line go to the NARROW width group (the one the Makefile's SCHED applies to); the WIDE
+# group and capi.hip are built with the defaults, as in the Makefile
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function"
+/opt/rocm/bin/hipcc $BASE -c capi.hip -o $OBJ/capi.o &
+/opt/rocm/bin/hipcc $BASE -c $OBJ/stubs.hip -o $OBJ/stubs.o &
+for v in rough_carpet rough_carpet2; do
+  /opt/rocm/bin/hipcc $BASE $* -c variants_$v.hip -o $OBJ/variants_$v.o &
+  /opt/rocm/bin/hipcc $BASE -DPTRWM_PART_WIDE -c variants_$v.hip -o $OBJ/variants_$v.wide.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libptrwm_hip.so $OBJ/capi.o $OBJ/variants_rough_carpet.o $OBJ/variants_rough_carpet2.o $OBJ/stubs.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libptrwm_hip.so $OBJ/capi.o $OBJ/stubs.o \
+  $OBJ/variants_rough_carpet.o $OBJ/variants_rough_carpet.wide.o $OBJ/variants_rough_carpet2.o $OBJ/variants_rough_carpet2.wide.o
 ls -la $OUT/libptrwm_hip.so
