@@ -746,3 +746,16 @@ def test_randomised_configurations_against_the_oracle(device):
                        text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
     assert "80 cases agree" in r.stdout
+
+
+def test_randomised_split_steps_against_the_fused_kernel(device):
+    """tools/fuzz_split.py, 60 random cases: ptrwm_split_propose / ptrwm_logdensity / ptrwm_split_accept reproduce
+    ptrwm_run bit for bit (states, log-densities, all statistics) for every target family, proposal and ladder shape."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_split.py"), "60", "3"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
+    assert "60 cases: split steps reproduce the fused kernel bit for bit" in r.stdout
