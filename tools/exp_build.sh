@@ -23,7 +23,7 @@ BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function"
 /opt/rocm/bin/hipcc $BASE -c $OBJ/stubs.hip -o $OBJ/stubs.o &
 for v in rough_carpet rough_carpet2; do
   /opt/rocm/bin/hipcc $BASE $* -c variants_$v.hip -o $OBJ/variants_$v.o &
-  /opt/rocm/bin/hipcc $BASE -DPTRWM_PART_WIDE -c variants_$v.hip -o $OBJ/variants_$v.wide.o &
+  /opt/rocm/bin/hipcc $BASE $PTRWM_EXP_WIDE_FLAGS -DPTRWM_PART_WIDE -c variants_$v.hip -o $OBJ/variants_$v.wide.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libptrwm_hip.so $OBJ/capi.o $OBJ/stubs.o \
