@@ -18,6 +18,11 @@
  * retains a pointer past the call, allocates device memory, or synchronises:
  * every entry point only enqueues kernels on `stream`.
  *
+ * Device contract (the usual HIP one): the device that owns `stream` and every
+ * pointer must be the CURRENT device of the calling thread (hipSetDevice); the
+ * library never switches devices.  The Python binding does this around every
+ * call (ptrwm_hip.on_device), so `device="cuda:1"` works without set_device.
+ *
  * All entry points return 0 on success or a negative PTRWM_E_* code; no C++
  * exception crosses this boundary.
  */

@@ -205,7 +205,12 @@ struct HybridRosenbrock {
     for (int i = 1; i < DP; ++i) {
       if (i < D) {
         const bool head = (tp.mask[i >> 6] >> (i & 63)) & 1ull;
-        const float parent = head ? y[0] : y[i - 1];
+        // select between the two VALUES: left alone the optimiser selects the INDEX (head ? 0 : i - 1), which makes
+        // y[] dynamically indexed and moves the whole vector to scratch memory (16 + 4 DP bytes per thread, found by
+        // tools/kernel_stats.py --check); the empty asm pins the second candidate in a register first
+        float prev = y[i - 1];
+        asm volatile("" : "+v"(prev));
+        const float parent = head ? y[0] : prev;
         const float r = y[i] - parent * parent;
         acc = fmaf(b * r, r, acc);
       }

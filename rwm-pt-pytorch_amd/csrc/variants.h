@@ -23,6 +23,15 @@ namespace ptrwm {
 #define PTRWM_WIDTHS_WIDE(X) X(100, true) X(80, false) X(104, false)
 #define PTRWM_WIDTHS(X) PTRWM_WIDTHS_NARROW(X) PTRWM_WIDTHS_WIDE(X)
 
+// The max-ILP group must stay at register widths <= 64 (at most 232 VGPRs measured): a wider entry belongs in
+// PTRWM_WIDTHS_WIDE.  (tools/kernel_stats.py --check, run by the Makefile, checks the compiled VGPR / AGPR counts too.)
+#define PTRWM_X_NARROW_OK(W, E) static_assert(W <= 64, "register widths above 64 belong in PTRWM_WIDTHS_WIDE (default scheduler)");
+PTRWM_WIDTHS_NARROW(PTRWM_X_NARROW_OK)
+#undef PTRWM_X_NARROW_OK
+#define PTRWM_X_WIDE_OK(W, E) static_assert(W > 64 && W <= PTRWM_MAX_DIM, "PTRWM_WIDTHS_WIDE holds the widths 65..PTRWM_MAX_DIM");
+PTRWM_WIDTHS_WIDE(PTRWM_X_WIDE_OK)
+#undef PTRWM_X_WIDE_OK
+
 struct WidthInfo {
   int dp;
   bool exact;
@@ -62,14 +71,21 @@ hipError_t launch_run(const KArgs &a, unsigned grid, bool full, hipStream_t stre
   auto kfull = ptrwm_step_kernel<Target, Proposal, DP, EXACT, true>;
   auto kprod = ptrwm_step_kernel<Target, Proposal, DP, EXACT, false>;
   if (lds > 48u * 1024u) {
-    // above the default dynamic-LDS allowance (wide ladders at large dim): raise it once per kernel
-    static const hipError_t raised = [&] {
+    // above the default dynamic-LDS allowance (wide ladders at large dim): raise it once per kernel AND per device
+    // (the attribute belongs to the function object of the device that is current when it is set; a process that
+    // samples on cuda:0 and later on cuda:1 must raise it on both)
+    constexpr int kMaxDevices = 64;
+    static unsigned long long raised_mask = 0;  // bit d: raised on device d (a race merely sets the attribute twice)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    const bool known = dev >= 0 && dev < kMaxDevices;
+    if (!known || !((__atomic_load_n(&raised_mask, __ATOMIC_ACQUIRE) >> dev) & 1ull)) {
       const int cap = (int)step_kernel_lds_bytes(kBlockThreads, DP);
       hipError_t e = hipFuncSetAttribute((const void *)kfull, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void *)kprod, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-      return e;
-    }();
-    if (raised != hipSuccess) return raised;
+      if (e != hipSuccess) return e;
+      if (known) __atomic_fetch_or(&raised_mask, 1ull << dev, __ATOMIC_RELEASE);
+    }
   }
   if (full)
     hipLaunchKernelGGL(kfull, dim3(grid), dim3(block), lds, stream, a);

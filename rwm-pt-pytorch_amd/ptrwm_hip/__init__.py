@@ -186,6 +186,32 @@ def _stream(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class on_device:
+    """Makes `device` the current HIP device around a C-ABI call and restores the previous one afterwards.
+
+    The C ABI launches on whatever device is current (the usual HIP contract, stated in include/ptrwm.h), while the
+    class API accepts `device='cuda:1'` without the caller ever calling `torch.cuda.set_device`: without this guard
+    the kernel would be launched on device 0 with device-1 pointers.  A no-op (two integer compares) when the device
+    is already current, so the per-step launch path stays at a few microseconds."""
+
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device: torch.device):
+        self.idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.prev = self.idx
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_device()
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
 @dataclass
 class Target:
     """Host-side description of a target density; tensors are kept alive by the owner."""
@@ -245,7 +271,8 @@ def logdensity(target: Target, x: torch.Tensor) -> torch.Tensor:
     xp = _require_device(x, "x", torch.float32)
     out = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
     desc = target.desc()
-    rc = lib.ptrwm_logdensity(C.byref(desc), xp, out.data_ptr(), x.shape[0], _stream(x.device))
+    with on_device(x.device):
+        rc = lib.ptrwm_logdensity(C.byref(desc), xp, out.data_ptr(), x.shape[0], _stream(x.device))
     if rc != 0:
         raise PTRWMError(rc, "ptrwm_logdensity")
     return out
@@ -261,9 +288,9 @@ def propose(proposal: Proposal, dim: int, n: int, seed: int = 0, ext_raw: Option
         if tuple(ext_raw.shape) != (n, T, ext_raw_per_step(proposal.kind, dim)):
             raise ValueError(f"ext_raw has shape {tuple(ext_raw.shape)}")
     out = torch.empty(n, T, dim, device=dev, dtype=torch.float32)
-    rc = lib.ptrwm_propose(
-        C.byref(desc), dim, T, n, _opt(ext_raw, "ext_raw", torch.float32), seed & (2**64 - 1), out.data_ptr(), _stream(dev)
-    )
+    with on_device(dev):
+        rc = lib.ptrwm_propose(C.byref(desc), dim, T, n, _opt(ext_raw, "ext_raw", torch.float32), seed & (2**64 - 1),
+                               out.data_ptr(), _stream(dev))
     if rc != 0:
         raise PTRWMError(rc, "ptrwm_propose")
     return out
@@ -275,7 +302,8 @@ def philox_raw(seed: int, c0: int, c1: int, c2: int, c3: int, n: int, device) ->
     out = torch.empty(n, 4, device=device, dtype=torch.int32)
     if not out.is_cuda:
         raise RuntimeError("philox_raw needs a ROCm device")
-    rc = lib.ptrwm_philox_raw(seed, c0, c1, c2, c3, n, out.data_ptr(), _stream(out.device))
+    with on_device(out.device):
+        rc = lib.ptrwm_philox_raw(seed, c0, c1, c2, c3, n, out.data_ptr(), _stream(out.device))
     if rc != 0:
         raise PTRWMError(rc, "ptrwm_philox_raw")
     return out.to(torch.int64) & 0xFFFFFFFF
@@ -318,6 +346,9 @@ class RunPlan:
         self.shape = (Cn, T, D)
         self.proposal_kind = proposal.kind
         self.device = state.device
+        for name, t in (("logp", logp), ("beta", beta), ("temp_scale", proposal.temp_scale)):
+            if t.device != self.device:
+                raise ValueError(f"{name} is on {t.device}, state on {self.device}: all tensors of a run live on one GPU")
         a = RunArgs()
         a.struct_size = C.sizeof(RunArgs)
         a.n_temps = T
@@ -347,6 +378,7 @@ class RunPlan:
         self._refs = (self._t, self._p, C.byref(self._t) if target is not None else None, C.byref(self._p), C.byref(a))
         self._keep = (target, proposal, state, logp, beta, n_accept, sq_jump, swap_accept, last_swap_ordinal)
         self._plain = True  # no per-launch buffers set in _a
+        self._guard = on_device(self.device)  # (after the checks above: they reject CPU tensors first)
 
     def launch(
         self,
@@ -398,7 +430,8 @@ class RunPlan:
                 raise ValueError("accept_flags must be [n_steps, n_chains, n_temps]")
             a.accept_flags = _opt(accept_flags, "accept_flags", torch.uint8)
             self._plain = plain
-        rc = self._lib.ptrwm_run(self._refs[2], self._refs[3], self._refs[4], _stream(self.device))
+        with self._guard:
+            rc = self._lib.ptrwm_run(self._refs[2], self._refs[3], self._refs[4], _stream(self.device))
         if rc != 0:
             raise PTRWMError(rc, "ptrwm_run")
 
@@ -425,8 +458,9 @@ class RunPlan:
             if tuple(ext_prop.shape) != (Cn, T, raw) or ext_u is None or tuple(ext_u.shape) != (Cn, T):
                 raise ValueError("ext_prop / ext_u of one step must be [n_chains, n_temps, raw] / [n_chains, n_temps]")
         self._plain = False
-        rc = self._lib.ptrwm_split_propose(self._refs[3], self._refs[4], D, props.data_ptr(), acc_u.data_ptr(),
-                                           _stream(self.device))
+        with self._guard:
+            rc = self._lib.ptrwm_split_propose(self._refs[3], self._refs[4], D, props.data_ptr(), acc_u.data_ptr(),
+                                               _stream(self.device))
         if rc != 0:
             raise PTRWMError(rc, "ptrwm_split_propose")
         return props
@@ -449,9 +483,10 @@ class RunPlan:
         a.ext_swap_u = _opt(ext_swap_u, "ext_swap_u", torch.float32)
         a.accept_flags = _opt(accept_flags, "accept_flags", torch.uint8)
         self._plain = False
-        rc = self._lib.ptrwm_split_accept(self._refs[4], D, props.data_ptr(), acc_u.data_ptr(),
-                                          _require_device(logp_proposed, "logp_proposed", torch.float32),
-                                          _stream(self.device))
+        with self._guard:
+            rc = self._lib.ptrwm_split_accept(self._refs[4], D, props.data_ptr(), acc_u.data_ptr(),
+                                              _require_device(logp_proposed, "logp_proposed", torch.float32),
+                                              _stream(self.device))
         if rc != 0:
             raise PTRWMError(rc, "ptrwm_split_accept")
 
@@ -467,7 +502,8 @@ class RunPlan:
         a.step0 = rng_step
         a.ext_swap_u = _opt(ext_swap_u, "ext_swap_u", torch.float32)
         self._plain = False  # per-launch fields of _a were touched: the next launch() rewrites them
-        rc = self._lib.ptrwm_swap_sweep(self._refs[4], D, event_index, rng_stream, _stream(self.device))
+        with self._guard:
+            rc = self._lib.ptrwm_swap_sweep(self._refs[4], D, event_index, rng_stream, _stream(self.device))
         if rc != 0:
             raise PTRWMError(rc, "ptrwm_swap_sweep")
 

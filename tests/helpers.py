@@ -179,3 +179,209 @@ def first_mismatch(a, b):
     neq = np.any((a != b).reshape(a.shape[0], -1), axis=1)
     idx = np.nonzero(neq)[0]
     return None if idx.size == 0 else int(idx[0])
+
+
+# (fixture, seed) tables of tests/golden/generate_golden.py (gen_rwm / gen_pt): the value `np.random.seed` received
+# just before the reference sampler was constructed (the initial state is drawn from the global NumPy RNG)
+RWM_FIXTURE_SEEDS = {
+    "rwm_rc15_normal": 42, "rwm_rc4_normal_beta": 43, "rwm_even_laplace": 44, "rwm_tm_uniform": 45,
+    "rwm_full_normal": 46, "rwm_hyb_laplace": 47, "rwm_gamma_normal": 48, "rwm_beta_uniform": 49,
+    "rwm_rc15s_normal": 50, "rwm_tms_normal": 51, "rwm_mvn_laplace": 52, "rwm_smvn_normal": 53,
+    "rwm_cube_uniform": 54, "rwm_funnel_normal": 55,
+}
+PT_FIXTURE_SEEDS = {"pt_rc15_geo8": 142, "pt_rc5_fine12": 143, "pt_tm15_t32": 144, "pt_even_t5": 145, "pt_hyb_t4": 146}
+
+
+def build_target_class(key, device):
+    """The drop-in target class for a golden target key, from the constructor arguments generate_golden.make_targets
+    gave the reference class (scaled variants: the reference's drawn scaling factors are installed afterwards)."""
+    import torch
+
+    import target_distributions as TD
+
+    c15 = [[-15.0] + [0.0] * 29, [0.0] * 30, [15.0] + [0.0] * 29]
+    cg = [list(np.linspace(-3, 1, 10)), list(np.linspace(0.5, -0.5, 10)), list(np.linspace(2, 4, 10))]
+    G = golden_targets()
+    make = {
+        "rc15_d30": lambda: TD.RoughCarpetDistributionTorch(30, device=device, mode_centers=[-15.0, 0.0, 15.0]),
+        "rc5_d30": lambda: TD.RoughCarpetDistributionTorch(30, device=device),
+        "rc4_d20": lambda: TD.RoughCarpetDistributionTorch(20, device=device, mode_centers=[-4.0, 0.0, 4.0],
+                                                           mode_weights=[0.2, 0.5, 0.3]),
+        "rc15s_d10": lambda: TD.RoughCarpetDistributionTorch(10, scaling=True, device=device,
+                                                             mode_centers=[-15.0, 0.0, 15.0]),
+        "tm_d50": lambda: TD.ThreeMixtureDistributionTorch(50, device=device),
+        "tm15_d30": lambda: TD.ThreeMixtureDistributionTorch(30, device=device, mode_centers=c15),
+        "tms_d10": lambda: TD.ThreeMixtureDistributionTorch(10, scaling=True, device=device, mode_centers=cg,
+                                                            mode_weights=[0.2, 0.3, 0.5]),
+        "full_d30": lambda: TD.FullRosenbrockTorch(30, device=device),
+        "full_d10": lambda: TD.FullRosenbrockTorch(10, a_coeff=0.1, b_coeff=2.0, mu=torch.linspace(0.5, 1.5, 9),
+                                                   device=device),
+        "even_d30": lambda: TD.EvenRosenbrockTorch(30, device=device),
+        "hyb_3_5": lambda: TD.HybridRosenbrockTorch(3, 5, device=device),
+        "hyb_5_4": lambda: TD.HybridRosenbrockTorch(5, 4, device=device),
+        "gamma_d50": lambda: TD.IIDGammaTorch(50, device=device),
+        "gamma_d5": lambda: TD.IIDGammaTorch(5, shape=3.5, scale=0.7, device=device),
+        "beta_d50": lambda: TD.IIDBetaTorch(50, device=device),
+        "beta_d5": lambda: TD.IIDBetaTorch(5, alpha=1.5, beta=4.0, device=device),
+        "mvn_d50": lambda: TD.MultivariateNormalTorch(50, device=device),
+        "smvn_d20": lambda: TD.ScaledMultivariateNormalTorch(
+            20, scaling_factors=G["smvn_d20"][0].params["scaling_factors"], device=device),
+        "cube_d5": lambda: TD.HypercubeTorch(5, device=device),
+        "funnel_d10": lambda: TD.NealFunnelTorch(10, device=device),
+    }
+    return make[key]()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Full-horizon parity with PROVEN flips (VERDICT r01 "next" #2).
+#
+# Two engines (the HIP kernel and the oracle, or - in the CPU self-test - two oracle runs) consume identical random
+# arrays.  They may legitimately disagree on a Metropolis or swap decision only where the uniform sits inside the
+# fp32 error band of its threshold.  `check_parity` walks every ladder to the END of the horizon: at the first step
+# where a ladder's decisions or states differ it recomputes that step's log-ratio in fp64 from the last agreed
+# state, ASSERTS the uniform is within the stated log-density tolerance of exp(ratio), then restarts both engines
+# from the oracle's state of that step and keeps comparing.  A wrong decision anywhere in the horizon fails.
+# ---------------------------------------------------------------------------------------------------------
+def logp_tol(l):
+    """Stated fp32 log-density tolerance (tests/test_gpu_engine_parity.py header): 4e-6 max(1, |l|) + 1e-4."""
+    return 4e-6 * np.maximum(1.0, np.abs(np.asarray(l, dtype=np.float64))) + 1e-4
+
+
+def events_upto(sc, swap_every, burn_in):
+    """Swap events with step_counter <= sc (multiples m * swap_every with burn_in < m * swap_every <= sc)."""
+    return max(0, sc // swap_every - burn_in // swap_every)
+
+
+def step_log_ratios(spec, prop, pre_state, ext_row, beta):
+    """fp64 log accept ratios beta_t (l(y_t) - l(x_t)) of ONE ladder for one step, and the pieces a proof needs.
+    pre_state [T, D] float32 (the last agreed state), ext_row [T, raw] the step's raw proposal randoms."""
+    T, D = pre_state.shape
+    inc = O.propose(prop.oracle(), D, 1, ext_raw=np.ascontiguousarray(ext_row, dtype=f32)[None])[0]  # fp32 arithmetic
+    x = np.ascontiguousarray(pre_state, dtype=f32)
+    y = (x + inc.astype(f32)).astype(f32)
+    l_x = O.logdensity(spec.oracle(), x, "f64")
+    l_y = O.logdensity(spec.oracle(), y, "f64")
+    with np.errstate(invalid="ignore"):
+        r = np.asarray(beta, dtype=np.float64) * (l_y - l_x)
+    return r, l_x, l_y, y
+
+
+def _prove_mh_flip(r, l_x, l_y, beta_t, u, slack, where):
+    assert np.isfinite(l_x) and np.isfinite(l_y), f"{where}: decisions differ although a log-density is not finite " \
+                                                  f"(l {l_x}, l' {l_y}): not an fp32-level flip"
+    tol_r = float(beta_t) * float(logp_tol(l_x) + logp_tol(l_y)) * slack
+    thr = float(np.exp(min(r, 0.0)))
+    gap = abs(float(u) - thr) if r < 0 else (0.0 if r <= tol_r else np.inf)
+    # |u - exp(r)| <= exp(r) * (beta * 2 * (4e-6 max(1, |l|) + 1e-4))  [+ one lattice step of u]
+    assert r <= tol_r and gap <= thr * tol_r + 6e-8, \
+        f"{where}: WRONG Metropolis decision: u = {float(u):.9g}, exp(r) = {np.exp(min(r, 50.0)):.9g} (r = {r:.6g}), " \
+        f"allowed |u - exp(r)| <= {thr * tol_r + 6e-8:.3g}"
+    return gap / max(thr * tol_r + 6e-8, 1e-300)
+
+
+def _prove_swap_flip(lm, beta, us, swap_mode, swap_order, ev_number, slack, where):
+    """Replays one swap event along the oracle's path in fp64 and asserts that at least one attempted pair has its
+    uniform inside the tolerance band of its threshold (so a different outcome is an fp32-level flip)."""
+    T = len(lm)
+    lm = np.array(lm, dtype=np.float64)
+    b = np.asarray(beta, dtype=np.float64)
+    seq = swap_order == O.ORDER_SEQUENTIAL
+    best = np.inf
+    for j in range(0 if seq else int(ev_number & 1), T - 1, 1 if seq else 2):
+        k = j + 1
+        with np.errstate(invalid="ignore", over="ignore"):
+            lpr = (b[j] - b[k]) * (lm[k] - lm[j])
+            thr = 1.0 if lpr >= 0 else float(np.exp(lpr))
+            mag = abs(b[j] * lm[k]) + abs(b[k] * lm[j]) + abs(b[j] * lm[j]) + abs(b[k] * lm[k])
+        accepted = (us[j] < thr) if np.isfinite(lpr) or lpr == -np.inf else False
+        if np.isfinite(lpr) and np.isfinite(mag):
+            tol = (abs(b[j] - b[k]) * float(logp_tol(lm[j]) + logp_tol(lm[k])) + 2.0 ** -22 * mag) * slack
+            if lpr < 0 or lpr <= tol:
+                best = min(best, abs(float(us[j]) - thr) / (thr * tol + 6e-8))
+        if accepted:
+            if swap_mode == O.SWAP_EXCHANGE:
+                lm[j], lm[k] = lm[k], lm[j]
+            else:
+                lm[j] = lm[k]
+    assert best <= 1.0, f"{where}: WRONG swap outcome: no attempted pair has its uniform within the fp32 band of its " \
+                        f"threshold (closest is {best:.3g} bands away)"
+    return best
+
+
+def check_parity(run_a, run_b, spec, prop, *, state, logp, beta, n_steps, burn_in, swap_every, swap_mode=O.SWAP_EXCHANGE,
+                 swap_order=O.ORDER_SEQUENTIAL, ext_prop, ext_u, ext_swap_u=None, exact_states, step0=0, slack=1.0,
+                 state_rtol=1e-4, state_atol=2e-5, max_flip_rate=1e-3, _depth=0, _flips=None):
+    """run_a / run_b: callables(**kw) -> dict with trace [n, C, T, D], trace_logp [n, C, T], accept_flags [n, C, T],
+    n_accept, sq_jump, swap_accept, last_swap_ordinal (engine A = the one under test, B = the oracle).
+    Returns the list of proven flips [(global step, ladder, kind, margin in tolerance bands)]."""
+    flips = [] if _flips is None else _flips
+    state = np.ascontiguousarray(state, dtype=f32)
+    Cn, T, D = state.shape
+    logp = np.ascontiguousarray(logp, dtype=f32).reshape(Cn, T)
+    beta = np.asarray(beta, dtype=f32)
+    if not exact_states:
+        slack = slack * 2.0  # the increments themselves differ by <= 2 ulp between the engines
+    kw = dict(state=state, logp=logp, beta=beta, step0=step0, n_steps=n_steps, burn_in=burn_in, swap_every=swap_every,
+              swap_mode=swap_mode, swap_order=swap_order, ext_prop=ext_prop, ext_u=ext_u,
+              ext_swap_u=ext_swap_u if T > 1 else None)
+    got, want = run_a(**kw), run_b(**kw)
+    ev0 = events_upto(step0, swap_every, burn_in)
+    for c in range(Cn):
+        fl = np.any(got["accept_flags"][:, c] != want["accept_flags"][:, c], axis=1)
+        g, w = got["trace"][:, c].reshape(n_steps, -1), want["trace"][:, c].reshape(n_steps, -1)
+        if exact_states:
+            same = np.all((g == w) | (np.isnan(g) & np.isnan(w)), axis=1)
+        else:
+            same = np.all(np.isclose(g, w, rtol=state_rtol, atol=state_atol, equal_nan=True), axis=1)
+        bad = np.nonzero(fl | ~same)[0]
+        if bad.size == 0:
+            # the whole segment agrees: integer bookkeeping must be identical, the jump sums equal to fp32 rounding
+            for k in ("n_accept", "swap_accept", "last_swap_ordinal"):
+                assert np.array_equal(got[k][c], want[k][c]), f"{k} of ladder {c} differs although every decision agrees"
+            np.testing.assert_allclose(got["sq_jump"][c], want["sq_jump"][c], rtol=1e-4, atol=1e-9)
+            continue
+        d = int(bad[0])
+        s_glob = step0 + d
+        where = f"ladder {c}, global step {s_glob}"
+        pre_x = want["trace"][d - 1, c] if d > 0 else state[c]
+        r, l_x, l_y, y = step_log_ratios(spec, prop, pre_x, ext_prop[d, c], beta)
+        sc = s_glob + 1
+        swap_due = T > 1 and sc > burn_in and sc % swap_every == 0
+        if fl[d]:
+            for t in np.nonzero(got["accept_flags"][d, c] != want["accept_flags"][d, c])[0]:
+                m = _prove_mh_flip(float(r[t]), float(l_x[t]), float(l_y[t]), beta[t], ext_u[d, c, t], slack,
+                                   f"{where}, temperature {t}")
+                flips.append((s_glob, c, "mh", m))
+        else:
+            assert swap_due, f"{where}: states differ although every decision agrees and no swap is due"
+            acc = want["accept_flags"][d, c].astype(bool)
+            lm = np.where(acc, l_y, l_x)
+            ev_rel = events_upto(sc, swap_every, burn_in) - 1 - ev0
+            m = _prove_swap_flip(lm, beta, ext_swap_u[ev_rel, c], swap_mode, swap_order,
+                                 ev0 + ev_rel, slack, where)
+            flips.append((s_glob, c, "swap", m))
+        # resynchronise from the oracle's state of step d and compare the rest of the horizon
+        if d + 1 < n_steps:
+            assert _depth < 12, f"{where}: more than 12 decision flips in one ladder"
+            ev_next = events_upto(sc, swap_every, burn_in) - ev0
+            check_parity(run_a, run_b, spec, prop, state=want["trace"][d, c][None], logp=want["trace_logp"][d, c][None],
+                         beta=beta, n_steps=n_steps - d - 1, burn_in=burn_in, swap_every=swap_every, swap_mode=swap_mode,
+                         swap_order=swap_order, ext_prop=np.ascontiguousarray(ext_prop[d + 1:, c:c + 1]),
+                         ext_u=np.ascontiguousarray(ext_u[d + 1:, c:c + 1]),
+                         ext_swap_u=None if ext_swap_u is None else np.ascontiguousarray(ext_swap_u[ev_next:, c:c + 1]),
+                         exact_states=exact_states, step0=sc, slack=slack / (1.0 if exact_states else 2.0),
+                         state_rtol=state_rtol, state_atol=state_atol, max_flip_rate=max_flip_rate, _depth=_depth + 1,
+                         _flips=flips)
+    if _depth == 0:
+        budget = 3 + max_flip_rate * n_steps * Cn * T
+        assert len(flips) <= budget, f"{len(flips)} decision flips in {n_steps * Cn * T} decisions: too many for fp32 " \
+                                     f"rounding (budget {budget:.1f})"
+    return flips
+
+
+def oracle_runner(spec, prop, precision="f32"):
+    """run_b for check_parity: the C oracle with per-step trace and accept flags."""
+    def run(**kw):
+        Cn, T = kw["state"].shape[:2]
+        return O.run(spec.oracle(), prop.oracle(), trace_chains=Cn, trace_temps=T, want_flags=True, precision=precision, **kw)
+    return run

@@ -5,8 +5,12 @@ Tolerances (stated once):
   * integer / index work (Philox words, accept counts given equal decisions, swap bookkeeping): exact
   * state updates x + scale*z (Normal proposal): bit-exact IEEE single
   * log-densities: |gpu - fp64 oracle| <= 4e-6 * max(1, |log p|) + 1e-4  (fp32 evaluation; v_exp/v_log 1 ulp)
-  * accept decisions: can only differ where |u - exp(r)| is inside that error; checked one step at a time
-    ("teacher forced") so one flip cannot cascade, agreement >= 99.9 % required
+  * accept / swap decisions: can only differ where |u - exp(r)| is inside that error.  Every run against the oracle
+    goes through helpers.check_parity: the FULL horizon is compared; at the first differing decision of a ladder the
+    step's beta (l' - l) is recomputed in fp64 from the last agreed state and |u - exp(r)| <= exp(r) beta 2 (4e-6
+    max(1, |l|) + 1e-4) is ASSERTED, then both engines restart from the oracle's state and the comparison continues
+    (tests/test_parity_checker.py shows that a wrong decision at step 15 fails).  Golden trajectories are also
+    replayed one step at a time ("teacher forced"), agreement >= 99.9 % required.
 """
 import os
 import zlib
@@ -58,6 +62,13 @@ def gpu_run(spec, prop, device, *, state, logp, beta, n_steps, trace_temps=0, wa
     if flags is not None:
         out["accept_flags"] = flags.cpu().numpy()
     return out
+
+
+def gpu_runner(spec, prop, device):
+    """run_a for helpers.check_parity: the HIP engine through the C ABI, per-step trace and accept flags on."""
+    def run(**kw):
+        return gpu_run(spec, prop, device, trace_temps=kw["state"].shape[1], want_flags=True, **kw)
+    return run
 
 
 def logp_close(got, want, extra_abs=1e-4):
@@ -197,24 +208,25 @@ def test_rwm_trajectory_matches_reference(device, name):
         np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
     logp_close(res["logp"][agree, 0], lchain[1:][agree])
 
-    # free run from the initial state: identical to the reference up to the first flipped decision (if any)
+    # free run from the initial state over the whole golden horizon: the oracle reproduces the reference's chain
+    # exactly (tests/test_oracle_golden.py); the kernel must follow it, any decision flip proven (check_parity)
     lp0 = E.logdensity(spec.engine(device), dev_t(chain[:1], device)).cpu().numpy().reshape(1, 1)
     burn = int(z["burn_in"])
-    free = gpu_run(spec, prop, device, state=chain[:1][None], logp=lp0, beta=[beta], step0=0, n_steps=total,
-                   burn_in=burn, ext_prop=z["raw"][:, None, None, :], ext_u=z["u"][:, None, None], trace_temps=1,
-                   want_flags=True)
-    first = H.first_mismatch(free["accept_flags"][:, 0, 0].astype(bool), moved)
-    upto = total if first is None else first
-    if exact:
-        assert np.array_equal(free["trace"][:upto, 0, 0], chain[1:upto + 1])
-    else:
-        np.testing.assert_allclose(free["trace"][:upto, 0, 0], chain[1:upto + 1], rtol=1e-4, atol=1e-5)
-    if first is None:
+    kw = dict(state=chain[:1][None], logp=lp0, beta=[beta], n_steps=total, burn_in=burn, swap_every=1,
+              ext_prop=np.ascontiguousarray(z["raw"][:, None, None, :]), ext_u=np.ascontiguousarray(z["u"][:, None, None]))
+    flips = H.check_parity(gpu_runner(spec, prop, device), H.oracle_runner(spec, prop), spec, prop, exact_states=exact, **kw)
+    free = gpu_run(spec, prop, device, step0=0, trace_temps=1, want_flags=True, **kw)
+    if not flips:
         N = int(z["n_samples"])
+        if exact:
+            assert np.array_equal(free["trace"][:, 0, 0], chain[1:])
+        else:
+            np.testing.assert_allclose(free["trace"][:, 0, 0], chain[1:], rtol=1e-4, atol=1e-5)
         assert int(free["n_accept"][0, 0]) == int(z["num_acceptances"])
         assert free["sq_jump"][0, 0] / N == pytest.approx(float(z["esjd"]), rel=1e-4)
-    else:  # a flip must sit where u is within the fp32 error of exp(r)
-        assert first > 20 or not exact
+    else:
+        first = flips[0][0]
+        assert np.allclose(free["trace"][:first, 0, 0], chain[1:first + 1], rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("name", PT_CASES)
@@ -227,13 +239,17 @@ def test_pt_trajectory_matches_reference(device, name):
     total, burn, se = rows - 1, int(z["burn_in"]), int(z["swap_every"])
     kw = dict(beta=beta, burn_in=burn, swap_every=se, swap_mode=E.SWAP_REFERENCE_COPY, swap_order=E.ORDER_SEQUENTIAL)
 
-    free = gpu_run(spec, prop, device, state=np.ascontiguousarray(chains[:, 0])[None], logp=lchains[:, 0][None],
-                   step0=0, n_steps=total, ext_prop=z["ext_prop"][:, None], ext_u=z["ext_u"][:, None],
-                   ext_swap_u=z["ext_swap_u"][:, None], trace_temps=T, **kw)
+    run_kw = dict(state=np.ascontiguousarray(chains[:, 0])[None], logp=lchains[:, 0][None], n_steps=total,
+                  ext_prop=np.ascontiguousarray(z["ext_prop"][:, None]), ext_u=np.ascontiguousarray(z["ext_u"][:, None]),
+                  ext_swap_u=np.ascontiguousarray(z["ext_swap_u"][:, None]), **kw)
+    # the whole golden horizon against the oracle (which reproduces the reference exactly), flips proven
+    flips = H.check_parity(gpu_runner(spec, prop, device), H.oracle_runner(spec, prop), spec, prop, exact_states=True,
+                           **run_kw)
+    free = gpu_run(spec, prop, device, step0=0, trace_temps=T, **run_kw)
     got = free["trace"][:, 0]  # [total, T, D]
     want = chains[:, 1:].transpose(1, 0, 2)
-    first = H.first_mismatch(got, want)
-    if first is None:
+    if not flips:
+        assert np.array_equal(got, want)
         assert int(free["swap_accept"].sum()) == int(z["num_swap_acceptances"])
         last = int(free["last_swap_ordinal"].max())
         assert free["swap_accept"].sum() / last == pytest.approx(float(z["swap_acceptance_rate"]), rel=1e-12)
@@ -243,7 +259,8 @@ def test_pt_trajectory_matches_reference(device, name):
         assert free["sq_jump"][0, 0] / (total - burn) == pytest.approx(float(z["esjd"]), rel=1e-4)
         logp_close(free["trace_logp"][:, 0], lchains[:, 1:].T)
     else:
-        assert first >= 10, f"{name}: leaves the reference trajectory at step {first}"
+        first = flips[0][0]
+        assert np.array_equal(got[:first], want[:first])
 
     # teacher forced: restart from the reference state at every step i (as replica i), one step each, the
     # step's place in the swap schedule kept through step0 -- done per residue class so step0 is shared
@@ -318,24 +335,15 @@ def test_external_randoms_vs_oracle(device, tkey, pkind, T, Cn, pkw, mode, order
     st, lp = start_state(spec, Cn, T, rng)
     kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=burn, swap_every=se, ext_prop=ext, ext_u=u,
               ext_swap_u=us if T > 1 else None, want_flags=True)
-    want = O.run(spec.oracle(), prop.oracle(), swap_mode=E.SWAP_MODES[mode], swap_order=E.SWAP_ORDERS[order],
-                 trace_chains=Cn, trace_temps=T, **kw)
-    got = gpu_run(spec, prop, device, trace_temps=T, swap_mode=E.SWAP_MODES[mode], swap_order=E.SWAP_ORDERS[order], **kw)
-    first = H.first_mismatch(got["accept_flags"], want["accept_flags"])
-    upto = N if first is None else first
-    assert upto >= 10
-    if pkind == "Normal":
-        assert np.array_equal(got["trace"][:upto], want["trace"][:upto])
-    else:
-        np.testing.assert_allclose(got["trace"][:upto], want["trace"][:upto], rtol=1e-4, atol=1e-5)
+    kw.pop("want_flags"), kw.pop("step0")
+    H.check_parity(gpu_runner(spec, prop, device), H.oracle_runner(spec, prop), spec, prop, exact_states=pkind == "Normal",
+                   swap_mode=E.SWAP_MODES[mode], swap_order=E.SWAP_ORDERS[order], **kw)
     # carried log-densities are those of the carried states (checked at the kernel's own states, so that the
     # <= 2 ulp increment differences of Laplace / UniformRadius cannot leak into this tolerance)
+    got = gpu_run(spec, prop, device, trace_temps=T, step0=0, swap_mode=E.SWAP_MODES[mode],
+                  swap_order=E.SWAP_ORDERS[order], **kw)
     own = O.logdensity(spec.oracle(), got["trace"].reshape(-1, spec.dim), "f64").reshape(got["trace_logp"].shape)
     logp_close(got["trace_logp"], own, extra_abs=3e-4)
-    if first is None:
-        for k in ("n_accept", "swap_accept", "last_swap_ordinal"):
-            assert np.array_equal(got[k], want[k]), k
-        np.testing.assert_allclose(got["sq_jump"], want["sq_jump"], rtol=1e-4, atol=1e-9)
 
 
 @pytest.mark.parametrize("tkey,pkind,T,Cn,pkw", SWEEP[:6], ids=[f"{s[0]}-{s[1]}-T{s[2]}" for s in SWEEP[:6]])
@@ -440,14 +448,8 @@ def test_every_register_width_vs_oracle(device, dim):
     us = rng.random((N // 4, Cn, T - 1)).astype(np.float32)
     kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=3, swap_every=4, ext_prop=ext, ext_u=u,
               ext_swap_u=us, want_flags=True)
-    want = O.run(spec.oracle(), prop.oracle(), trace_chains=Cn, trace_temps=T, **kw)
-    got = gpu_run(spec, prop, device, trace_temps=T, **kw)
-    first = H.first_mismatch(got["accept_flags"], want["accept_flags"])
-    upto = N if first is None else first
-    assert upto >= 6
-    assert np.array_equal(got["trace"][:upto], want["trace"][:upto])
-    if first is None:
-        assert np.array_equal(got["n_accept"], want["n_accept"]) and np.array_equal(got["swap_accept"], want["swap_accept"])
+    kw.pop("want_flags"), kw.pop("step0")
+    H.check_parity(gpu_runner(spec, prop, device), H.oracle_runner(spec, prop), spec, prop, exact_states=True, **kw)
     # Philox mode at the same width: decisions agree with the oracle's restated stream
     kw2 = dict(state=st, logp=lp, beta=beta, step0=5, n_steps=N, burn_in=3, swap_every=4, seed=dim * 7919, chain_offset=3,
                want_flags=True)
@@ -492,19 +494,12 @@ def test_generic_width_targets_vs_oracle(device, cls, dim, params, pkind):
     kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=4, swap_every=5,
               ext_prop=_ext_arrays(rng, pkind, N, Cn, T, raw), ext_u=rng.random((N, Cn, T)).astype(np.float32),
               ext_swap_u=rng.random((N // 5, Cn, T - 1)).astype(np.float32), want_flags=True)
-    want = O.run(spec.oracle(), prop.oracle(), trace_chains=Cn, trace_temps=T, **kw)
-    got = gpu_run(spec, prop, device, trace_temps=T, **kw)
-    first = H.first_mismatch(got["accept_flags"], want["accept_flags"])
-    upto = N if first is None else first
-    assert upto >= 8
-    if pkind == "Normal":
-        assert np.array_equal(got["trace"][:upto], want["trace"][:upto])
-    else:
-        np.testing.assert_allclose(got["trace"][:upto], want["trace"][:upto], rtol=1e-4, atol=1e-5)
+    kw.pop("want_flags"), kw.pop("step0")
+    H.check_parity(gpu_runner(spec, prop, device), H.oracle_runner(spec, prop), spec, prop, exact_states=pkind == "Normal",
+                   **kw)
+    got = gpu_run(spec, prop, device, trace_temps=T, step0=0, **kw)
     own = O.logdensity(spec.oracle(), got["trace"].reshape(-1, dim), "f64").reshape(got["trace_logp"].shape)
     logp_close(got["trace_logp"], own, extra_abs=3e-4)
-    if first is None:
-        assert np.array_equal(got["n_accept"], want["n_accept"]) and np.array_equal(got["swap_accept"], want["swap_accept"])
 
 
 @pytest.mark.parametrize("T,Cn", [(64, 3), (33, 2), (63, 5), (21, 4), (2, 100), (1, 1), (32, 1),
@@ -520,20 +515,12 @@ def test_ladder_shapes_vs_oracle(device, T, Cn):
     N = 40
     for order, mode in (("sequential", "exchange"), ("even_odd", "exchange"), ("sequential", "reference_copy"),
                         ("even_odd", "reference_copy")):
-        kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=2, swap_every=3,
+        kw = dict(state=st, logp=lp, beta=beta, n_steps=N, burn_in=2, swap_every=3,
                   ext_prop=rng.standard_normal((N, Cn, T, 30)).astype(np.float32),
                   ext_u=rng.random((N, Cn, T)).astype(np.float32),
                   ext_swap_u=rng.random((N // 3, Cn, T - 1)).astype(np.float32) if T > 1 else None,
-                  swap_order=E.SWAP_ORDERS[order], swap_mode=E.SWAP_MODES[mode], want_flags=True)
-        want = O.run(spec.oracle(), prop.oracle(), trace_chains=Cn, trace_temps=T, **kw)
-        got = gpu_run(spec, prop, device, trace_temps=T, **kw)
-        first = H.first_mismatch(got["accept_flags"], want["accept_flags"])
-        upto = N if first is None else first
-        assert upto >= 8
-        assert np.array_equal(got["trace"][:upto], want["trace"][:upto])
-        if first is None:
-            for k in ("n_accept", "swap_accept", "last_swap_ordinal"):
-                assert np.array_equal(got[k], want[k]), (k, order, mode)
+                  swap_order=E.SWAP_ORDERS[order], swap_mode=E.SWAP_MODES[mode])
+        H.check_parity(gpu_runner(spec, prop, device), H.oracle_runner(spec, prop), spec, prop, exact_states=True, **kw)
 
 
 def test_zero_chains_and_support_edges(device):
@@ -707,15 +694,8 @@ def test_wide_ladder_with_large_dim_vs_oracle(device, T, dim):
               ext_prop=rng.standard_normal((N, Cn, T, dim)).astype(np.float32),
               ext_u=rng.random((N, Cn, T)).astype(np.float32),
               ext_swap_u=rng.random((N // 2, Cn, T - 1)).astype(np.float32), want_flags=True)
-    want = O.run(spec.oracle(), prop.oracle(), trace_chains=Cn, trace_temps=T, **kw)
-    got = gpu_run(spec, prop, device, trace_temps=T, **kw)
-    first = H.first_mismatch(got["accept_flags"], want["accept_flags"])
-    upto = N if first is None else first
-    assert upto >= 6
-    assert np.array_equal(got["trace"][:upto], want["trace"][:upto])
-    if first is None:
-        for k in ("n_accept", "swap_accept", "last_swap_ordinal"):
-            assert np.array_equal(got[k], want[k]), k
+    kw.pop("want_flags"), kw.pop("step0")
+    H.check_parity(gpu_runner(spec, prop, device), H.oracle_runner(spec, prop), spec, prop, exact_states=True, **kw)
     # production (non-trace) variant at the same shape: runs and keeps the log-densities consistent with the states
     got2 = gpu_run(spec, prop, device, state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=1, swap_every=2, seed=5)
     chk = O.logdensity(spec.oracle(), got2["state"].reshape(-1, dim), "f64").reshape(Cn, T)

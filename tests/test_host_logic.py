@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+import helpers as H
 import ptrwm_hip
 from algorithms import (ParallelTemperingRWM_GPU_Optimized, RandomWalkMH_GPU_Optimized, RWM_GPU_Optimized,
                         geometric_beta_ladder)
@@ -101,6 +102,40 @@ def test_initial_state_rule():
     assert len(alg.chain) == 1 and alg.get_curr_state().shape == (6,)
     with pytest.raises(NotImplementedError):
         alg.step()
+
+
+@pytest.mark.parametrize("fixture", sorted(H.RWM_FIXTURE_SEEDS) + sorted(H.PT_FIXTURE_SEEDS))
+def test_initial_state_equals_the_references(fixture):
+    """a18 pinned to the reference itself: every golden trajectory stores the `x0` the reference sampler started
+    from (interfaces/metropolis.py:21-64 after `np.random.seed(seed)`; PT: broadcast to fp32 rows,
+    pt_rwm_gpu_optimized.py:478-484).  The drop-in's rule, given the drop-in's own target class (its NAME decides
+    the branch), must reproduce it bit for bit - and so must the sampler classes built on top of it."""
+    z = H.load(fixture + ".npz")
+    key = str(z["target_key"])
+    target = H.build_target_class(key, "cpu")
+    is_pt = fixture.startswith("pt_")
+    seed = (H.PT_FIXTURE_SEEDS if is_pt else H.RWM_FIXTURE_SEEDS)[fixture]
+    np.random.seed(seed)
+    got = np.asarray(initial_state_for(target, target.dim))
+    want = z["x0"]
+    if is_pt:  # the reference PT class stores the start as a float32 row
+        assert want.dtype == np.float32
+        assert np.array_equal(torch.as_tensor(got, dtype=torch.float32).numpy(), want)
+    else:
+        assert want.dtype == np.float64 and np.array_equal(got.astype(np.float64), want)
+        assert got.dtype == (np.float32 if "Beta" in target.get_name() else np.float64)
+    # the same through the sampler classes (what a user gets): the constructor consumes the global NumPy RNG once
+    np.random.seed(seed)
+    if is_pt:
+        alg = ParallelTemperingRWM_GPU_Optimized(target.dim, float(z["var"]), target, beta_ladder=list(z["beta_ladder"]),
+                                                 device="cpu")
+        assert np.array_equal(np.asarray(alg._initial_state, dtype=np.float32), want)
+    else:
+        alg = RandomWalkMH_GPU_Optimized(target.dim, 0.1, target, device="cpu")
+        assert np.array_equal(np.asarray(alg.chain[0], dtype=np.float64), want)
+    # ... and it is the first row of the reference's stored chain
+    first = z["chains"][:, 0] if is_pt else z["chain"][:1]
+    assert np.array_equal(first, np.broadcast_to(np.asarray(want, np.float32), first.shape))
 
 
 def test_proposal_parameters_and_validation():
@@ -339,3 +374,44 @@ def test_driver_target_factory_calls_construct():
     fused = [t for t in made if t is not made[-1]]
     for t in fused:
         assert t.engine_target().dim == t.dim
+
+
+def test_abi_calls_run_with_the_tensors_device_current(monkeypatch):
+    """ptrwm_hip.on_device: every C-ABI call is made with the tensors' device current (HIP launches on the current
+    device whatever the pointers say) and the previous device is restored, also when the call raises.  Checked
+    without a GPU by recording what the guard does to torch.cuda's current device."""
+    cur = {"dev": 0, "log": []}
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: cur["dev"])
+
+    def set_device(i):
+        cur["dev"] = int(i)
+        cur["log"].append(int(i))
+
+    monkeypatch.setattr(torch.cuda, "set_device", set_device)
+    with ptrwm_hip.on_device(torch.device("cuda", 1)):
+        assert cur["dev"] == 1
+    assert cur["dev"] == 0 and cur["log"] == [1, 0]
+    cur["log"].clear()
+    with ptrwm_hip.on_device(torch.device("cuda", 0)):  # already current: nothing to do
+        assert cur["dev"] == 0
+    assert cur["log"] == []
+    with pytest.raises(KeyError):
+        with ptrwm_hip.on_device(torch.device("cuda", 3)):
+            assert cur["dev"] == 3
+            raise KeyError("boom")
+    assert cur["dev"] == 0
+    # a bare "cuda" device means the current one
+    cur["dev"] = 2
+    g = ptrwm_hip.on_device(torch.device("cuda"))
+    assert g.idx == 2
+    # every entry point that reaches the library goes through the guard
+    import inspect
+
+    src = inspect.getsource(ptrwm_hip)
+    calls = [ln for ln in src.splitlines() if "lib.ptrwm_" in ln and "(" in ln and "ptrwm_strerror" not in ln
+             and "ptrwm_abi_version" not in ln and "ptrwm_ext_raw_per_step" not in ln and "ptrwm_has_variant" not in ln]
+    assert len(calls) >= 7
+    lines = src.splitlines()
+    for ln in calls:
+        i = lines.index(ln)
+        assert lines[i - 1].strip().startswith("with "), f"unguarded C-ABI call: {ln.strip()}"

@@ -1,0 +1,139 @@
+"""The parity comparator itself (tests/helpers.check_parity), exercised on the CPU with the oracle standing in for
+BOTH engines: one side is fed deliberately altered randoms, so that it makes (a) no different decision, (b) a
+legitimate fp32-level flip (uniform one lattice step across the threshold), (c) a WRONG Metropolis decision at step 15,
+(d) a WRONG swap outcome.  (a) and (b) must pass - (b) with the flip proven and the run resynchronised to the end of
+the horizon - and (c), (d) must fail.  This is the guard that the GPU parity tests cover their full horizon."""
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import oracle as O
+
+f32 = np.float32
+
+
+def _case(pkind="Normal", T=6, Cn=4, N=40, burn=5, se=4, seed=0):
+    spec = H.target_spec("rc15_d30")
+    beta = (0.05 ** (np.arange(T) / (T - 1))).astype(f32)
+    prop = H.proposal_spec(pkind, 30, beta, base_variance_scalar=2.38**2 / 30) if pkind == "Normal" else \
+        H.proposal_spec(pkind, 30, beta, base_variance_vector=np.full(30, 0.2, f32))
+    rng = np.random.default_rng(seed)
+    st = np.zeros((Cn, T, 30), f32)
+    lp = np.broadcast_to(O.logdensity(spec.oracle(), np.zeros((1, 30), f32)).astype(f32), (Cn, T)).copy()
+    ext = (rng.standard_normal((N, Cn, T, 30)) if pkind == "Normal" else rng.random((N, Cn, T, 30))).astype(f32)
+    kw = dict(state=st, logp=lp, beta=beta, n_steps=N, burn_in=burn, swap_every=se, ext_prop=ext,
+              ext_u=rng.random((N, Cn, T)).astype(f32),
+              ext_swap_u=rng.random((N // se - burn // se, Cn, T - 1)).astype(f32), exact_states=pkind == "Normal")
+    return spec, prop, kw
+
+
+def _tamper(run, step0_of_tamper, edit):
+    """An 'engine' that is the oracle fed edited copies of the random arrays (edits addressed by GLOBAL step)."""
+    def run_a(**kw):
+        kw = dict(kw)
+        kw["ext_u"] = kw["ext_u"].copy()
+        kw["ext_swap_u"] = None if kw["ext_swap_u"] is None else kw["ext_swap_u"].copy()
+        edit(kw)
+        return run(**kw)
+    return run_a
+
+
+def test_identical_engines_have_no_flips():
+    spec, prop, kw = _case()
+    run = H.oracle_runner(spec, prop)
+    assert H.check_parity(run, run, spec, prop, **kw) == []
+    # fp64 arithmetic against fp32 arithmetic on the same randoms: any flip must be provable (usually none)
+    flips = H.check_parity(H.oracle_runner(spec, prop, "f64"), run, spec, prop, **{**kw, "exact_states": False})
+    assert len(flips) <= 2
+
+
+@pytest.mark.parametrize("pkind", ["Normal", "Laplace"])
+def test_a_legitimate_flip_is_proven_and_the_run_resynchronised(pkind):
+    spec, prop, kw = _case(pkind)
+    run = H.oracle_runner(spec, prop)
+    s0, c0, t0 = 15, 2, 3
+    # place the shared uniform of (s0, c0, t0) just ABOVE exp(r): beyond the fp32 evaluation error of exp(r) (~1e-5
+    # relative) but well inside the stated band (~3e-4 beta relative), so the oracle rejects ...
+    base = run(state=kw["state"], logp=kw["logp"], beta=kw["beta"], step0=0, n_steps=s0, burn_in=kw["burn_in"],
+               swap_every=kw["swap_every"], swap_mode=0, swap_order=0, ext_prop=kw["ext_prop"][:s0], ext_u=kw["ext_u"][:s0],
+               ext_swap_u=kw["ext_swap_u"])
+    r, *_ = H.step_log_ratios(spec, prop, base["trace"][s0 - 1, c0], kw["ext_prop"][s0, c0], kw["beta"])
+    for t in range(len(r)):  # pick a temperature whose ratio is comfortably negative
+        if -3.0 < r[t] < -0.05 and kw["beta"][t] > 0.2:
+            t0 = t
+            break
+    thr = np.exp(r[t0])
+    eps = 1e-4 * float(kw["beta"][t0])
+    kw["ext_u"][s0, c0, t0] = f32(thr * (1 + eps))
+    assert kw["ext_u"][s0, c0, t0] > thr
+
+    def edit(k):  # ... and give engine A a uniform just BELOW it (A accepts)
+        i = s0 - k["step0"]
+        if 0 <= i < k["n_steps"] and k["state"].shape[0] == kw["state"].shape[0]:
+            k["ext_u"][i, c0, t0] = f32(thr * (1 - eps))
+
+    flips = H.check_parity(_tamper(run, 0, edit), run, spec, prop, **kw)
+    assert len(flips) == 1 and flips[0][:3] == (s0, c0, "mh") and flips[0][3] <= 1.0
+
+
+def test_a_wrong_metropolis_decision_at_step_15_fails():
+    spec, prop, kw = _case()
+    run = H.oracle_runner(spec, prop)
+    want = run(state=kw["state"], logp=kw["logp"], beta=kw["beta"], step0=0, n_steps=kw["n_steps"],
+               burn_in=kw["burn_in"], swap_every=kw["swap_every"], swap_mode=0, swap_order=0, ext_prop=kw["ext_prop"],
+               ext_u=kw["ext_u"], ext_swap_u=kw["ext_swap_u"])
+    s0 = 15
+    rej = np.argwhere((want["accept_flags"][s0] == 0) & (kw["ext_u"][s0] > 0.3))  # a clear rejection at step 15
+    c0, t0 = rej[0]
+
+    def edit(k):
+        i = s0 - k["step0"]
+        if 0 <= i < k["n_steps"] and k["state"].shape[0] == kw["state"].shape[0]:
+            k["ext_u"][i, c0, t0] = 0.0  # engine A accepts where it must not
+
+    with pytest.raises(AssertionError, match="WRONG Metropolis decision"):
+        H.check_parity(_tamper(run, 0, edit), run, spec, prop, **kw)
+
+
+@pytest.mark.parametrize("order", [O.ORDER_SEQUENTIAL, O.ORDER_EVEN_ODD])
+@pytest.mark.parametrize("mode", [O.SWAP_EXCHANGE, O.SWAP_REFERENCE_COPY])
+def test_a_wrong_swap_outcome_fails(order, mode):
+    spec, prop, kw = _case(seed=3)
+    kw.update(swap_mode=mode, swap_order=order)
+    run = H.oracle_runner(spec, prop)
+    assert H.check_parity(run, run, spec, prop, **kw) == []
+    base = run(step0=0, **{k: v for k, v in kw.items() if k != "exact_states"})
+
+    def make_edit(ev0, c0):
+        def edit(k):
+            if k["state"].shape[0] != kw["state"].shape[0] or k["step0"] != 0:
+                return
+            row = k["ext_swap_u"][ev0, c0]
+            # invert clear decisions of this event: uniforms near 0 where they were large and vice versa
+            k["ext_swap_u"][ev0, c0] = np.where(row > 0.5, 1e-6, 0.999999).astype(f32)
+        return edit
+
+    # an (event, ladder) whose inverted uniforms really change the outcome
+    for ev0, c0 in [(e, c) for e in range(2, kw["ext_swap_u"].shape[0]) for c in range(kw["state"].shape[0])]:
+        tampered = _tamper(run, 0, make_edit(ev0, c0))
+        out = tampered(step0=0, **{k: v for k, v in kw.items() if k != "exact_states"})
+        if not np.array_equal(out["trace"], base["trace"]):
+            break
+    else:
+        pytest.fail("no tampering changed the trajectory")
+    with pytest.raises(AssertionError, match="WRONG swap outcome"):
+        H.check_parity(tampered, run, spec, prop, **kw)
+
+
+def test_stat_mismatch_without_decision_difference_fails():
+    spec, prop, kw = _case()
+    run = H.oracle_runner(spec, prop)
+
+    def run_a(**k):
+        out = run(**k)
+        out["n_accept"] = out["n_accept"].copy()
+        out["n_accept"][0, 0] += 1  # bookkeeping bug
+        return out
+
+    with pytest.raises(AssertionError, match="n_accept"):
+        H.check_parity(run_a, run, spec, prop, **kw)
