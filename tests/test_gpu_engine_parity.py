@@ -333,9 +333,8 @@ def test_external_randoms_vs_oracle(device, tkey, pkind, T, Cn, pkw, mode, order
     n_ev = N // se - burn // se
     us = rng.random((n_ev, Cn, max(T - 1, 1))).astype(np.float32)[:, :, :T - 1]
     st, lp = start_state(spec, Cn, T, rng)
-    kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=burn, swap_every=se, ext_prop=ext, ext_u=u,
-              ext_swap_u=us if T > 1 else None, want_flags=True)
-    kw.pop("want_flags"), kw.pop("step0")
+    kw = dict(state=st, logp=lp, beta=beta, n_steps=N, burn_in=burn, swap_every=se, ext_prop=ext, ext_u=u,
+              ext_swap_u=us if T > 1 else None)
     H.check_parity(gpu_runner(spec, prop, device), H.oracle_runner(spec, prop), spec, prop, exact_states=pkind == "Normal",
                    swap_mode=E.SWAP_MODES[mode], swap_order=E.SWAP_ORDERS[order], **kw)
     # carried log-densities are those of the carried states (checked at the kernel's own states, so that the
@@ -446,9 +445,8 @@ def test_every_register_width_vs_oracle(device, dim):
     ext = _ext_arrays(rng, "Normal", N, Cn, T, dim)
     u = rng.random((N, Cn, T)).astype(np.float32)
     us = rng.random((N // 4, Cn, T - 1)).astype(np.float32)
-    kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=3, swap_every=4, ext_prop=ext, ext_u=u,
-              ext_swap_u=us, want_flags=True)
-    kw.pop("want_flags"), kw.pop("step0")
+    kw = dict(state=st, logp=lp, beta=beta, n_steps=N, burn_in=3, swap_every=4, ext_prop=ext, ext_u=u,
+              ext_swap_u=us)
     H.check_parity(gpu_runner(spec, prop, device), H.oracle_runner(spec, prop), spec, prop, exact_states=True, **kw)
     # Philox mode at the same width: decisions agree with the oracle's restated stream
     kw2 = dict(state=st, logp=lp, beta=beta, step0=5, n_steps=N, burn_in=3, swap_every=4, seed=dim * 7919, chain_offset=3,
@@ -491,10 +489,9 @@ def test_generic_width_targets_vs_oracle(device, cls, dim, params, pkind):
     rng = np.random.default_rng(zlib.crc32(f"{cls}{dim}{pkind}".encode()))
     st, lp = start_state(spec, Cn, T, rng)
     raw = O.ext_raw_per_step(prop.kind, dim)
-    kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=4, swap_every=5,
+    kw = dict(state=st, logp=lp, beta=beta, n_steps=N, burn_in=4, swap_every=5,
               ext_prop=_ext_arrays(rng, pkind, N, Cn, T, raw), ext_u=rng.random((N, Cn, T)).astype(np.float32),
-              ext_swap_u=rng.random((N // 5, Cn, T - 1)).astype(np.float32), want_flags=True)
-    kw.pop("want_flags"), kw.pop("step0")
+              ext_swap_u=rng.random((N // 5, Cn, T - 1)).astype(np.float32))
     H.check_parity(gpu_runner(spec, prop, device), H.oracle_runner(spec, prop), spec, prop, exact_states=pkind == "Normal",
                    **kw)
     got = gpu_run(spec, prop, device, trace_temps=T, step0=0, **kw)
@@ -690,11 +687,10 @@ def test_wide_ladder_with_large_dim_vs_oracle(device, T, dim):
     cst = float(-0.5 * dim * np.log(2 * np.pi) + 0.5 * np.log(prec.astype(np.float64)).sum())
     spec = H.TargetSpec(O.TARGET_DIAG_GAUSSIAN, dim, (cst,), (0,), mean, prec, cls="MultivariateNormalTorch")
     st, lp = start_state(spec, Cn, T, rng)
-    kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=1, swap_every=2,
+    kw = dict(state=st, logp=lp, beta=beta, n_steps=N, burn_in=1, swap_every=2,
               ext_prop=rng.standard_normal((N, Cn, T, dim)).astype(np.float32),
               ext_u=rng.random((N, Cn, T)).astype(np.float32),
-              ext_swap_u=rng.random((N // 2, Cn, T - 1)).astype(np.float32), want_flags=True)
-    kw.pop("want_flags"), kw.pop("step0")
+              ext_swap_u=rng.random((N // 2, Cn, T - 1)).astype(np.float32))
     H.check_parity(gpu_runner(spec, prop, device), H.oracle_runner(spec, prop), spec, prop, exact_states=True, **kw)
     # production (non-trace) variant at the same shape: runs and keeps the log-densities consistent with the states
     got2 = gpu_run(spec, prop, device, state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=1, swap_every=2, seed=5)

@@ -4,6 +4,11 @@
     python tools/check_all_variants.py            # all (target, proposal) pairs, one child process each
     python tools/check_all_variants.py 0 2        # one pair in this process (target kind 0, proposal kind 2)
 
+Fixture kernels: the full horizon against the oracle on shared external randoms, for a narrow ladder (T = 3, one
+wavefront) and a ladder wider than a wavefront (T = 66: workgroup barriers, > 48 KB of dynamic LDS at the large widths);
+every differing decision must be a PROVEN fp32-level flip (tests/helpers.check_parity), there are no retries.
+Production kernels: Philox mode against the oracle's restated stream, and bit-identity with their fixture twin.
+
 A miscompiled variant shows up as a mismatch or as a GPU fault of the child (this is how a scheduler-flag miscompile of
 the width-80 UniformRadius fixture kernels was found)."""
 import os
@@ -67,43 +72,67 @@ def one_pair(tk, pk):
         spec, x0 = make_spec(H, tk, dim, rng)
         small = tk in (2, 3, 4, 6)
         sc = (0.02 if small else 1.0) * 2.38**2 / dim
-        if pk == 0:
-            prop = H.proposal_spec(pname, dim, beta, base_variance_scalar=sc)
-        elif pk == 1:
-            prop = H.proposal_spec(pname, dim, beta, base_variance_vector=np.full(dim, sc, f32))
-        else:
-            prop = H.proposal_spec(pname, dim, beta, base_radius=float(np.sqrt(sc * dim)))
+        def make_prop(b):
+            if pk == 0:
+                return H.proposal_spec(pname, dim, b, base_variance_scalar=sc)
+            if pk == 1:
+                return H.proposal_spec(pname, dim, b, base_variance_vector=np.full(dim, sc, f32))
+            return H.proposal_spec(pname, dim, b, base_radius=float(np.sqrt(sc * dim)))
+
+        prop = make_prop(beta)
         st = np.broadcast_to(x0.astype(f32), (Cn, T, dim)).copy()
         lp = np.broadcast_to(O.logdensity(spec.oracle(), x0[None].astype(f32)).astype(f32), (Cn, T)).copy()
         raw = E.ext_raw_per_step(prop.kind, dim)
-        kw = dict(beta=beta, step0=0, n_steps=N, burn_in=burn, swap_every=se)
         dt = lambda a, d=torch.float32: torch.tensor(np.ascontiguousarray(a), device=dev, dtype=d)  # noqa: E731
-        ok_full, first = False, None
-        for attempt in range(3):  # an fp32-level decision flip in the first two steps: try other randoms
-            ep = rng.standard_normal((N, Cn, T, raw)).astype(f32)
+
+        def ext_arrays(n, c, t):
+            ep = rng.standard_normal((n, c, t, raw)).astype(f32)
             if pk == 1:
-                ep = rng.random((N, Cn, T, raw)).astype(f32)
+                ep = rng.random((n, c, t, raw)).astype(f32)
             elif pk == 2:
-                ep[..., -1] = rng.random((N, Cn, T)).astype(f32)
-            eu, es = rng.random((N, Cn, T)).astype(f32), rng.random((N // se, Cn, T - 1)).astype(f32)
-            want = O.run(spec.oracle(), prop.oracle(), state=st, logp=lp, ext_prop=ep, ext_u=eu, ext_swap_u=es,
-                         trace_chains=Cn, trace_temps=T, want_flags=True, **kw)
-            s_d, l_d = dt(st), dt(lp)
-            trace = torch.zeros(N, Cn, T, dim, device=dev)
-            flags = torch.zeros(N, Cn, T, dtype=torch.uint8, device=dev)
-            nacc = torch.zeros(Cn, T, dtype=torch.int64, device=dev)
-            E.run(spec.engine(dev), prop.engine(dev), state=s_d, logp=l_d, beta=dt(beta), step0=0, n_steps=N, burn_in=burn,
-                  swap_every=se, trace=trace, accept_flags=flags, ext_prop=dt(ep), ext_u=dt(eu), ext_swap_u=dt(es),
-                  n_accept=nacc)
+                ep[..., -1] = rng.random((n, c, t)).astype(f32)
+            return ep, rng.random((n, c, t)).astype(f32), rng.random((max(1, n // se), c, t - 1)).astype(f32)
+
+        cur = {"prop": prop}  # the proposal (one scale per temperature) of the ladder being checked
+
+        def engine(**k):
+            """the fixture variant through the C ABI: per-step trace and accept flags (run_a of check_parity)"""
+            c, t = k["state"].shape[:2]
+            n = k["n_steps"]
+            s_d, l_d = dt(k["state"]), dt(k["logp"])
+            out = {"n_accept": torch.zeros(c, t, dtype=torch.int64, device=dev),
+                   "sq_jump": torch.zeros(c, t, dtype=torch.float64, device=dev),
+                   "swap_accept": torch.zeros(c, t, dtype=torch.int64, device=dev),
+                   "last_swap_ordinal": torch.zeros(c, t, dtype=torch.int64, device=dev)}
+            trace = torch.zeros(n, c, t, dim, device=dev)
+            tlp = torch.zeros(n, c, t, device=dev)
+            flags = torch.zeros(n, c, t, dtype=torch.uint8, device=dev)
+            E.run(spec.engine(dev), cur["prop"].engine(dev), state=s_d, logp=l_d, beta=dt(k["beta"]), step0=k["step0"], n_steps=n,
+                  burn_in=k["burn_in"], swap_every=k["swap_every"], swap_mode=k["swap_mode"], swap_order=k["swap_order"],
+                  trace=trace, trace_logp=tlp, accept_flags=flags, ext_prop=dt(k["ext_prop"]), ext_u=dt(k["ext_u"]),
+                  ext_swap_u=None if k["ext_swap_u"] is None or k["ext_swap_u"].shape[0] == 0 else dt(k["ext_swap_u"]), **out)
             torch.cuda.synchronize()
-            first = H.first_mismatch(flags.cpu().numpy(), want["accept_flags"])
-            upto = N if first is None else first
-            same = np.allclose(trace.cpu().numpy()[:upto], want["trace"][:upto], rtol=3e-5, atol=3e-5, equal_nan=True)
-            if not same:
-                break
-            if upto >= 2:
-                ok_full = True
-                break
+            res = {a: b.cpu().numpy() for a, b in out.items()}
+            res.update(trace=trace.cpu().numpy(), trace_logp=tlp.cpu().numpy(), accept_flags=flags.cpu().numpy())
+            return res
+
+        # fixture variant, narrow ladder (one wavefront) and a ladder wider than a wavefront (workgroup barriers, more than
+        # 48 KB of dynamic LDS at the large widths): the FULL horizon against the oracle, every decision flip proven
+        # (tests/helpers.check_parity) - no retries
+        ok_full, first = True, None
+        for (Tn, Cw, Nw) in ((T, Cn, N), (66, 2, 4)):
+            bw = beta if Tn == T else (0.05 ** (np.arange(Tn) / (Tn - 1))).astype(f32)
+            pw = prop if Tn == T else make_prop(bw)
+            stw = np.broadcast_to(x0.astype(f32), (Cw, Tn, dim)).copy()
+            lpw = np.broadcast_to(lp[0, 0], (Cw, Tn)).copy()
+            ep, eu, es = ext_arrays(Nw, Cw, Tn)
+            cur["prop"] = pw
+            try:
+                H.check_parity(engine, H.oracle_runner(spec, pw), spec, pw, state=stw, logp=lpw, beta=bw, n_steps=Nw,
+                               burn_in=burn, swap_every=se, ext_prop=ep, ext_u=eu, ext_swap_u=es, exact_states=pk == 0,
+                               state_rtol=3e-5, state_atol=3e-5)
+            except AssertionError as e:
+                ok_full, first = False, f"T={Tn}: {str(e)[:200]}"
         # production variant, Philox: the final log-densities must belong to the final states, counts must be close to
         # the oracle's on the same stream
         s_d, l_d = dt(st), dt(lp)
@@ -129,8 +158,8 @@ def one_pair(tk, pk):
         ok_prod &= torch.equal(s_f, s_d) and torch.equal(l_f, l_d) and torch.equal(nacc_f, nacc) and torch.equal(tr[-1], s_d)
         if not (ok_full and ok_prod):
             bad += 1
-            print(f"  MISMATCH target {tk} proposal {pname} dim {dim}: fixture ok={ok_full} (first flip {first}) production ok={ok_prod}", flush=True)
-    print(f"pair target {tk} proposal {pname}: {len(WIDTH_DIMS)} widths x 2 variants, {bad} bad", flush=True)
+            print(f"  MISMATCH target {tk} proposal {pname} dim {dim}: fixture ok={ok_full} ({first}) production ok={ok_prod}", flush=True)
+    print(f"pair target {tk} proposal {pname}: {len(WIDTH_DIMS)} widths x (fixture narrow + wide ladder, production), {bad} bad", flush=True)
     return bad
 
 

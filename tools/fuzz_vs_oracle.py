@@ -3,9 +3,10 @@
     python tools/fuzz_vs_oracle.py [n_cases] [seed]
 
 Each case draws a target family with random parameters, a dimension in 1..104, a ladder of 1..256 temperatures, a
-proposal, swap mode / order / period, burn-in, a chain offset and a launch split, runs both engines on the same
-external randoms and compares the per-step traces (identical up to the first fp32-level decision flip, which must be
-rare) and, when no flip occurred, all four statistics."""
+proposal, swap mode / order / period, burn-in and a chain offset, runs both engines on the same external randoms and
+compares them over the FULL horizon with tests/helpers.check_parity: per-step traces identical (Normal: bit for bit),
+every differing Metropolis or swap decision PROVEN to sit inside the fp32 band of its threshold, both engines then
+restarted from the oracle's state; all four statistics exact on every agreeing segment."""
 import os
 import sys
 
@@ -114,61 +115,46 @@ def main():
         if case < first_case:
             continue
         print(f"case {case}: {spec.cls} dim {dim} T {T} C {Cn} {pk} {order} {mode} N {N} se {se} burn {burn}", flush=True)
-        want = O.run(spec.oracle(), prop.oracle(), state=st, logp=lp, n_steps=N, trace_chains=Cn, trace_temps=T,
-                     want_flags=True, **kw, **ext)
-        # the engine: same run in one launch with per-step trace
         dt = lambda a, d=torch.float32: torch.tensor(np.ascontiguousarray(a), device=dev, dtype=d)  # noqa: E731
-        s_d, l_d = dt(st), dt(lp)
-        stats = {k: torch.zeros(Cn, T, dtype=(torch.float64 if k == "sq_jump" else torch.int64), device=dev)
-                 for k in ("n_accept", "sq_jump", "swap_accept", "last_swap_ordinal")}
-        trace = torch.zeros(N, Cn, T, dim, device=dev)
-        flags = torch.zeros(N, Cn, T, dtype=torch.uint8, device=dev)
-        E.run(spec.engine(dev), prop.engine(dev), state=s_d, logp=l_d, beta=dt(beta), step0=0, n_steps=N, burn_in=burn,
-              swap_every=se, swap_mode=kw["swap_mode"], swap_order=kw["swap_order"], chain_offset=kw["chain_offset"],
-              trace=trace, accept_flags=flags, ext_prop=dt(ep), ext_u=dt(ext["ext_u"]),
-              ext_swap_u=None if ext["ext_swap_u"] is None or n_ev == 0 else dt(ext["ext_swap_u"]), **stats)
-        torch.cuda.synchronize()
-        gf, wf = flags.cpu().numpy(), want["accept_flags"]
-        first = H.first_mismatch(gf, wf)
-        upto = N if first is None else first
-        g_full, w_full = trace.cpu().numpy(), want["trace"]
-        # a swap decision can flip at fp32 level too (log-densities differ in the last bits): if the first trace
-        # difference appears exactly at a swap step, compare up to that step only and count the flip
-        close = np.isclose(g_full, w_full, rtol=2e-5, atol=2e-5, equal_nan=True).reshape(N, -1).all(1)
-        if not close[:upto].all():
-            s_bad = int(np.argmin(close[:upto]))
-            sc = s_bad + 1
-            if T > 1 and sc > burn and sc % se == 0:
-                upto, first = s_bad, s_bad
-        g_all, w_all = g_full[:upto], w_full[:upto]
-        if pk == "Normal":  # x + scale * z with contraction off: bit-exact
-            ok_trace = np.array_equal(g_all, w_all, equal_nan=True)
-        else:  # hardware log2 / reciprocal against libm / division: last-bit differences in the increments
-            ok_trace = np.allclose(g_all, w_all, rtol=2e-5, atol=2e-5, equal_nan=True)
-        ok_stats = True
-        if first is None:
-            for k in ("n_accept", "swap_accept", "last_swap_ordinal"):
-                ok_stats &= np.array_equal(stats[k].cpu().numpy(), want[k])
-            ok_stats &= np.allclose(stats["sq_jump"].cpu().numpy(), want["sq_jump"], rtol=1e-4, atol=1e-6)
-        else:
-            flips += 1
-        tag = f"case {case:3d}: {spec.cls:30s} dim {dim:3d} T {T:3d} C {Cn:2d} {pk:13s} {order:10s} {mode:14s} N {N:2d} se {se} burn {burn}"
-        print(tag, "ok" if ok_trace and ok_stats else "MISMATCH", "" if first is None else f"(first decision flip at step {first})")
-        if not (ok_trace and ok_stats):
-            g_tr, w_tr = trace.cpu().numpy()[:upto], want["trace"][:upto]
-            bad = np.argwhere(~(np.isclose(g_tr, w_tr, rtol=2e-5, atol=2e-5) | (np.isnan(g_tr) & np.isnan(w_tr))))
-            print("  trace ok:", ok_trace, "stats ok:", ok_stats, "first flip:", first, "mismatching trace entries:", len(bad))
-            if len(bad):
-                s0, c0, t0, d0 = bad[0]
-                print("  first at step", s0, "chain", c0, "temp", t0, "dim", d0, "got", g_tr[s0, c0, t0, d0], "want", w_tr[s0, c0, t0, d0])
-                print("  flags there got/want", gf[s0, c0, t0], wf[s0, c0, t0])
-            for k in ("n_accept", "swap_accept", "last_swap_ordinal", "sq_jump"):
-                g, w = stats[k].cpu().numpy(), want[k]
-                if not np.allclose(g, w, rtol=1e-4, atol=1e-6):
-                    i = np.argwhere(~np.isclose(g, w, rtol=1e-4, atol=1e-6))[0]
-                    print("  ", k, "differs at", i, "got", g[tuple(i)], "want", w[tuple(i)])
+
+        def engine(**k):
+            """the engine through the C ABI with per-step trace and accept flags (run_a of check_parity)"""
+            c, t = k["state"].shape[:2]
+            n = k["n_steps"]
+            s_d, l_d = dt(k["state"]), dt(k["logp"])
+            out = {a: torch.zeros(c, t, dtype=(torch.float64 if a == "sq_jump" else torch.int64), device=dev)
+                   for a in ("n_accept", "sq_jump", "swap_accept", "last_swap_ordinal")}
+            trace = torch.zeros(n, c, t, dim, device=dev)
+            tlp = torch.zeros(n, c, t, device=dev)
+            flags = torch.zeros(n, c, t, dtype=torch.uint8, device=dev)
+            es = k["ext_swap_u"]
+            E.run(spec.engine(dev), prop.engine(dev), state=s_d, logp=l_d, beta=dt(k["beta"]), step0=k["step0"], n_steps=n,
+                  burn_in=k["burn_in"], swap_every=k["swap_every"], swap_mode=k["swap_mode"], swap_order=k["swap_order"],
+                  chain_offset=kw["chain_offset"], trace=trace, trace_logp=tlp, accept_flags=flags,
+                  ext_prop=dt(k["ext_prop"]), ext_u=dt(k["ext_u"]),
+                  ext_swap_u=None if es is None or es.shape[0] == 0 else dt(es), **out)
+            torch.cuda.synchronize()
+            res = {a: b.cpu().numpy() for a, b in out.items()}
+            res.update(trace=trace.cpu().numpy(), trace_logp=tlp.cpu().numpy(), accept_flags=flags.cpu().numpy())
+            return res
+
+        # the FULL horizon: every differing decision must be a proven fp32-level flip, after which both engines restart
+        # from the oracle's state (tests/helpers.check_parity); bookkeeping exact on every agreeing segment
+        es = ext["ext_swap_u"]
+        if T > 1 and es is not None and es.shape[0] == 0:
+            es = np.zeros((1, Cn, T - 1), f32)
+        try:
+            fl = H.check_parity(engine, H.oracle_runner(spec, prop), spec, prop, state=st, logp=lp, beta=beta, n_steps=N,
+                                burn_in=burn, swap_every=se, swap_mode=kw["swap_mode"], swap_order=kw["swap_order"],
+                                ext_prop=ep, ext_u=ext["ext_u"], ext_swap_u=es, exact_states=pk == "Normal",
+                                state_rtol=2e-5, state_atol=2e-5)
+        except AssertionError as e:
+            print(f"case {case:3d}: MISMATCH {e}")
             sys.exit(1)
-    print(f"{n_cases} cases agree; {flips} had an fp32-level decision flip (MH or swap) before the end")
+        flips += len(fl)
+        tag = f"case {case:3d}: {spec.cls:30s} dim {dim:3d} T {T:3d} C {Cn:2d} {pk:13s} {order:10s} {mode:14s} N {N:2d} se {se} burn {burn}"
+        print(tag, "ok", "" if not fl else f"({len(fl)} proven flip(s): {[(f[0], f[2]) for f in fl]})")
+    print(f"{n_cases} cases agree; {flips} proven fp32-level decision flip(s) (MH or swap), every case compared to its end")
     assert flips <= max(3, n_cases // 8), "too many decision flips for fp32-level differences"
 
 
