@@ -215,9 +215,11 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
         if self._trace_mode != "none":
             rows = self._run.traced_rows(n_steps, self.thin)
             if self._trace is None or self._rows_used + rows > self._trace_rows:
-                # no (or too small a) pre-allocation: grow the device-side chain storage
+                # no (or too small a) pre-allocation: grow the device-side chain storage GEOMETRICALLY (at least
+                # doubling), so that a step()-by-step() run copies O(N) rows in total, not O(N^2); `_rows_used` /
+                # `chain_indices` stay the logical length
                 old, old_lp, used = self._trace, self._trace_logp, self._rows_used
-                self._alloc_trace(max(used, 1) + rows)
+                self._alloc_trace(max(max(used, 1) + rows, 2 * self._trace_rows, 64))
                 if old is not None and used:
                     self._trace[:used] = old[:used]
                     self._trace_logp[:used] = old_lp[:used]

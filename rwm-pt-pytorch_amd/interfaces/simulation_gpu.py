@@ -67,9 +67,17 @@ class MCMCSimulation_GPU:
         self.algorithm.reset()
 
     def has_run(self):
-        if getattr(self.algorithm, "pre_allocated_chain", None) is not None:
-            return self.algorithm.chain_index > 1
-        return len(self.algorithm.chain) > 1
+        """Has the sampler taken a step?  Decided from host-side counters wherever they exist (the reference reads
+        `pre_allocated_chain` / `chain_index`, simulation_gpu.py:160-161); `len(chain)` - for the PT class a lazy
+        property that copies the whole cold chain to the host and turns it into a Python list - only as the last
+        resort for samplers that have nothing else."""
+        alg = self.algorithm
+        for counter in ("step_counter", "total_steps"):  # PT class / RWM class: plain Python ints
+            if isinstance(getattr(alg, counter, None), int):
+                return getattr(alg, counter) > 0
+        if getattr(alg, "pre_allocated_chain", None) is not None:
+            return alg.chain_index > 1
+        return len(alg.chain) > 1
 
     def generate_samples(self, progress_bar=True, as_list=True):
         """Run the sampler; returns the post-burn-in chain (list of lists like the reference, or the

@@ -266,6 +266,132 @@ def test_pt_iterative_ladder_on_device(device):
         assert abs(alg._estimate_swap_rate(hi, lo, 50000) - 0.234) < 0.03
 
 
+def test_the_two_gpu_drivers_calls_and_reads(device):
+    """Everything the reference's two GPU experiment drivers do to the samplers, with their own keyword sets and at toy
+    size: experiment_pt_GPU.py:217-279 (constructor call incl. the iterative-ladder knobs and `dtype=`, then
+    `generate_samples(progress_bar=False)`, `algorithm.swap_acceptance_rate`, `pt_expected_squared_jump_distance()`,
+    the JSON it writes, `algorithm.get_cold_chain_gpu()` for the trace plot) and experiment_RWM_GPU.py:246-266,344-353
+    (proposal_config form, `acceptance_rate()`, `expected_squared_jump_distance()`, `algorithm.get_chain_gpu()`); plus
+    the diagnostic keys tests/quick_test_optimizations.py:94-99 prints."""
+    import json
+    import warnings
+
+    dim, n, burn = 10, 400, 50
+    target = RoughCarpetDistributionTorch(dim, device=device, mode_centers=[-15.0, 0.0, 15.0])
+    pt_esjds, pt_rates, times = [], [], []
+    for target_swap_rate in (0.2, 0.3):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            sim = MCMCSimulation_GPU(
+                dim=dim, sigma=2.38**2 / dim, num_iterations=n, algorithm=ParallelTemperingRWM_GPU_Optimized,
+                target_dist=target, symmetric=True, pre_allocate=True, seed=1, burn_in=burn, device=str(device),
+                beta_ladder=None, swap_acceptance_rate=target_swap_rate, iterative_temp_spacing=True,
+                N_samples_swap_est=2000, iterative_tolerance=0.01, iterative_max_pn_steps=50, iterative_fail_tol_factor=3.0,
+                dtype=torch.float64)
+        # `use_double_precision` callers are TOLD that states are computed and stored in float32 (not a silent change)
+        assert any("float32" in str(x.message) for x in w)
+        chain = sim.generate_samples(progress_bar=False)
+        assert isinstance(chain, list) and len(chain) == n and len(chain[0]) == dim
+        alg = sim.algorithm
+        assert alg.get_name() == "PT_RWM_GPU_ULTRA_FUSED_ITERATIVE_LADDER"
+        assert isinstance(alg.beta_ladder, list) and alg.beta_ladder[0] == 1.0 and alg.num_chains == len(alg.beta_ladder)
+        pt_rates.append(alg.swap_acceptance_rate)
+        pt_esjds.append(sim.pt_expected_squared_jump_distance())
+        times.append(0.1)
+        assert isinstance(pt_rates[-1], float) and 0.0 <= pt_rates[-1] <= 1.0 and pt_esjds[-1] >= 0.0
+        cold = alg.get_cold_chain_gpu().cpu().numpy()
+        assert cold.shape == (n + burn + 1, dim)
+        assert np.array_equal(cold[1 + burn:], np.asarray(chain, dtype=np.float32))
+        assert len(alg.chain) == n + burn + 1  # the lazy list form the fallback branch of the driver reads
+        assert alg.num_swap_attempts == (n + burn) // alg.swap_every * (alg.num_chains - 1) - burn // alg.swap_every * (alg.num_chains - 1)
+    data = {"target_distribution": target.get_name(), "dimension": dim, "num_iterations": n, "seed": 1, "total_time": 0.2,
+            "max_esjd": max(pt_esjds), "max_actual_acceptance_rate": pt_rates[int(np.argmax(pt_esjds))],
+            "max_constr_acceptance_rate": 0.2, "expected_squared_jump_distances": pt_esjds, "acceptance_rates": pt_rates,
+            "swap_acceptance_rates_range": [0.2, 0.3], "times": times}
+    assert json.loads(json.dumps(data))["acceptance_rates"] == pt_rates  # plain floats: serialisable as the driver does
+    info = sim.algorithm.get_diagnostic_info()
+    for k in ("batch_matrix_multiply", "precomputed_randoms", "clone_free_swaps", "kernel_fusion", "memory_allocated_mb"):
+        assert k in info
+    sim.algorithm.performance_summary()
+
+    for cfg in ({"name": "Normal", "params": {"base_variance_scalar": 2.38**2 / dim}},
+                {"name": "Laplace", "params": {"base_variance_vector": torch.full((dim,), 0.5)}},
+                {"name": "UniformRadius", "params": {"base_radius": 2.0}}):
+        sim = MCMCSimulation_GPU(dim=dim, proposal_config=cfg, num_iterations=n, algorithm=RandomWalkMH_GPU_Optimized,
+                                 target_dist=target, symmetric=True, pre_allocate=True, seed=3, burn_in=burn,
+                                 device=str(device))
+        chain = sim.generate_samples(progress_bar=False)
+        assert len(chain) == n and len(chain[0]) == dim
+        acc, esjd = sim.acceptance_rate(), sim.expected_squared_jump_distance()
+        assert isinstance(acc, float) and 0.0 < acc < 1.0 and esjd > 0.0
+        json.dumps({"acceptance_rates": [acc], "expected_squared_jump_distances": [esjd]})
+        assert hasattr(sim.algorithm, "get_chain_gpu")
+        chain_data = sim.algorithm.get_chain_gpu().cpu().numpy()
+        assert chain_data.shape == (n + burn + 1, dim) and np.array_equal(chain_data[1 + burn:], np.asarray(chain, np.float32))
+        assert sim.algorithm.get_name() == f"RWM_GPU_FUSED_{cfg['name']}"
+        sim.algorithm.performance_comparison_summary()
+
+
+def _ladder_cases():
+    import json
+    import os
+
+    with open(os.path.join(H.GOLDEN, "reference_ladders.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("case", sorted(_ladder_cases()["cases"]))
+def test_iterative_ladder_matches_the_references_ladders(device, case):
+    """a17 / f2 pinned to the reference: tests/golden/reference_ladders.json holds, per (target, swap-acceptance target),
+    the ladders 24 independent constructions of the REFERENCE's `_construct_iterative_ladder`
+    (pt_rwm_gpu_optimized.py:283-426) produced on CPU.  The engine's construction (same Robbins-Monro recursion,
+    typical samples and log-densities on the device through the HIP kernel) over 24 seeds must agree with that
+    distribution: ladder length (equal when the reference's never varies, else means within 4 combined standard
+    errors) and every common rung's mean beta within 4 combined standard errors (the two-sample z statistic; 4 rather
+    than 3 because ~90 rungs are tested), with the RMS z over the rungs below 2."""
+    ref = _ladder_cases()
+    c = ref["cases"][case]
+    tkey = case.split("@")[0]
+    meta = ref["targets"][tkey]
+    target = H.build_target_class(tkey, device)
+    assert type(target).__name__ == meta["class"] and target.dim == meta["dim"]
+    dim = meta["dim"]
+    n_seeds = len(c["seeds"])
+    ladders = []
+    for s in range(n_seeds):
+        torch.manual_seed(77000 + s)
+        np.random.seed(77000 + s)
+        alg = ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target, True, iterative_temp_spacing=True,
+                                                 swap_acceptance_rate=c["swap_target"],
+                                                 N_samples_swap_est=ref["n_samples_swap_est"], swap_every=10,
+                                                 device=device)
+        lad = alg.beta_ladder
+        assert lad[0] == 1.0 and lad[-1] == pytest.approx(0.01) and all(a > b for a, b in zip(lad, lad[1:]))
+        ladders.append(lad)
+    lens = np.array([len(l) for l in ladders], dtype=np.float64)
+    ref_lens = np.array([len(l) for l in c["ladders"]], dtype=np.float64)
+    if ref_lens.std() == 0:
+        assert np.all(lens == ref_lens[0]), (case, sorted(set(lens)), ref_lens[0])
+    else:
+        se = np.sqrt(lens.var(ddof=1) / len(lens) + ref_lens.var(ddof=1) / len(ref_lens))
+        assert abs(lens.mean() - ref_lens.mean()) <= 4 * se + 1e-9, (case, lens.mean(), ref_lens.mean(), se)
+    n_common = int(min(lens.min(), ref_lens.min()))
+    got = np.array([l[:n_common] for l in ladders])
+    want = np.array([l[:n_common] for l in c["ladders"]])
+    z = []
+    for k in range(1, n_common):  # rung 0 is beta = 1 by construction
+        if k == n_common - 1 and np.all(want[:, k] == want[0, k]):  # the appended beta_min
+            assert np.allclose(got[:, k], want[0, k])
+            continue
+        se = np.sqrt(got[:, k].var(ddof=1) / len(got) + want[:, k].var(ddof=1) / len(want))
+        zk = (got[:, k].mean() - want[:, k].mean()) / max(se, 1e-12)
+        assert abs(zk) <= 4.0, f"{case} rung {k}: engine {got[:, k].mean():.6f} vs reference {want[:, k].mean():.6f}, z = {zk:.2f}"
+        # and the spread of a single construction is the reference's (same estimator noise): within a factor 2.5
+        assert got[:, k].std(ddof=1) <= 2.5 * want[:, k].std(ddof=1) + 1e-6
+        z.append(zk)
+    assert np.sqrt(np.mean(np.square(z))) < 2.0, (case, z)
+
+
 def test_baseline_config3_properties(device):
     """BASELINE.json configs[2] at full size: RoughCarpet dim 30, 32 geometric temperatures, swap_every 10,
     65 536 ladders.  Size-independent properties: determinism, exchange conserves the replica multiset,
@@ -309,6 +435,133 @@ def test_baseline_config3_properties(device):
     assert e.num_swap_attempts == (4 * 16 + 4 * 15) * C
     rates = e.mh_acceptance_rates()
     assert ((rates > 0.1) & (rates < 0.6)).all()
+
+
+@pytest.mark.parametrize("cfg", ["configs[3]", "configs[4]"])
+def test_baseline_config4_and_5_shard_properties(device, cfg):
+    """The per-GPU shards of BASELINE.json configs[3] (PT, EvenRosenbrock dim 30, Laplace proposal, 32 temperatures,
+    65 536 of the 524 288 ladders) and configs[4] (ThreeMixture dim 50, UniformRadius proposal, 64 temperatures,
+    131 072 of the 1 048 576 ladders: 1.7 GB of state) at FULL per-GPU size, through size-independent properties:
+    determinism and invisibility of launch splits, swap-attempt arithmetic, carried log-densities == the engine's
+    log-density of the carried states, agreement with the oracle on the first 64 ladders of the same Philox stream,
+    and the whole-job summary (all-reduce at world size 1) equal to the local one."""
+    from algorithms.sharding import allreduce_summary
+
+    np.random.seed(1234)  # EvenRosenbrock starts at 1e-8 N(0,1) drawn from the global NumPy RNG
+    if cfg == "configs[3]":
+        dim, T, C, offset = 30, 32, 65536, 3 * 65536  # the shard rank 3 of 8 owns
+        target = EvenRosenbrockTorch(dim, device=device)
+        proposal = LaplaceProposal(dim, torch.full((dim,), 0.004), 1.0, device, torch.float32)
+        spec, pspec = H.target_spec("even_d30"), None
+        pspec = H.proposal_spec("Laplace", dim, geometric_beta_ladder(T), base_variance_vector=np.full(dim, 0.004, np.float32))
+    else:
+        dim, T, C, offset = 50, 64, 131072, 5 * 131072
+        target = ThreeMixtureDistributionTorch(dim, device=device)
+        proposal = UniformRadiusProposal(dim, 2.4, 1.0, device, torch.float32)
+        spec = H.target_spec("tm_d50")
+        pspec = H.proposal_spec("UniformRadius", dim, geometric_beta_ladder(T), base_radius=2.4)
+    ladder = geometric_beta_ladder(T)
+    burn, se, n = 10, 10, 50
+
+    def make():
+        np.random.seed(1234)
+        return ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target, beta_ladder=ladder, swap_every=se, burn_in=burn,
+                                                  device=device, num_replicas=C, seed=777, chain_offset=offset,
+                                                  trace="none", proposal_distribution=proposal)
+
+    a, b = make(), make()
+    a._advance(burn + n)
+    b._advance(23)
+    b._advance(burn + n - 23)
+    assert torch.equal(a._run.state, b._run.state) and torch.equal(a._run.logp, b._run.logp)
+    for k in ("n_accept", "swap_accept", "last_ord"):
+        assert torch.equal(getattr(a._run, k), getattr(b._run, k)), k
+    assert torch.allclose(a._run.sq_jump, b._run.sq_jump, rtol=1e-12)
+    x0 = np.asarray(a._initial_state, np.float32)
+    del b
+    torch.cuda.empty_cache()
+    events = (burn + n) // se - burn // se
+    assert a.num_swap_attempts == events * (T - 1) * C
+    assert int(a._run.swap_accept[:, -1].sum()) == 0 and torch.isfinite(a._run.state).all()
+    # carried log-densities are the engine's log-densities of the carried states (same kernel functor: tight)
+    sub = slice(C - 2048, C)
+    lp = target.log_density(a._run.state[sub].reshape(-1, dim)).view(2048, T)
+    assert torch.allclose(lp, a._run.logp[sub], rtol=2e-6, atol=2e-4)
+    # oracle on the first 64 ladders of this shard, same Philox stream (global ladder ids offset .. offset + 63)
+    n_cmp = 64
+    st = np.broadcast_to(x0, (n_cmp, T, dim)).copy()
+    lp0 = np.broadcast_to(O.logdensity(spec.oracle(), x0[None]).astype(np.float32), (n_cmp, T)).copy()
+    want = O.run(spec.oracle(), pspec.oracle(), state=st, logp=lp0, beta=np.float32(ladder), step0=0, n_steps=burn + n,
+                 burn_in=burn, swap_every=se, seed=777, chain_offset=offset)
+    g_acc = a._run.n_accept[:n_cmp].cpu().numpy()
+    assert g_acc.sum() / want["n_accept"].sum() == pytest.approx(1.0, rel=3e-3)
+    assert np.mean(g_acc == want["n_accept"]) > 0.9
+    assert a._run.swap_accept[:n_cmp].sum().item() / max(1, want["swap_accept"].sum()) == pytest.approx(1.0, rel=1e-2)
+    # whole-job summary at world size 1 == the local summary
+    local = a._run.summary()
+    total = allreduce_summary(local, device)
+    assert total["n_replicas"] == C and total["post_burn_steps"] == n and total["swap_attempts"] == a.num_swap_attempts
+    assert torch.equal(total["accept_count"], local["accept_count"])
+    assert torch.allclose(total["esjd"], local["sq_jump_sum"] / (C * n), rtol=1e-12)
+    assert total["swap_acceptance_rate"] == pytest.approx(int(local["swap_accept_count"].sum()) / a.num_swap_attempts)
+    rates = a.mh_acceptance_rates()
+    assert ((rates > 0.02) & (rates < 0.9)).all()
+
+
+def test_two_gpu_processes_equal_one(device, tmp_path):
+    """Multi-process readiness on one GPU: two FRESH child processes (tests/mp_gpu_worker.py), world size 2 over gloo,
+    both on cuda:0, own ladders [0, C) and [C, 2C) via chain_offset.  Their concatenated final states, log-densities
+    and acceptance counts are bit-identical to ONE process running 2C ladders, and both ranks hold the same all-reduced
+    whole-job summary, equal to the single process's."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from algorithms.sharding import allreduce_summary
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mp_gpu_worker as W
+
+    C, steps = 1000, 60
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mp_gpu_worker.py")
+    outs = [str(tmp_path / f"rank{r}.npz") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(C), str(steps), outs[r]],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    parts = [np.load(o) for o in outs]
+    one = W.build(device, 2 * C, 0)
+    one._advance(steps)
+    assert np.array_equal(np.concatenate([p["state"] for p in parts]), one._run.state.cpu().numpy())
+    assert np.array_equal(np.concatenate([p["logp"] for p in parts]), one._run.logp.cpu().numpy())
+    assert np.array_equal(np.concatenate([p["n_accept"] for p in parts]), one._run.n_accept.cpu().numpy())
+    want = allreduce_summary(one._run.summary(), torch.device("cpu"))
+    for p in parts:  # every rank holds the whole-job summary
+        assert int(p["sum_n_replicas"]) == 2 * C and int(p["sum_post_burn_steps"]) == want["post_burn_steps"]
+        assert int(p["sum_swap_attempts"]) == want["swap_attempts"]
+        assert np.array_equal(p["sum_accept_count"], want["accept_count"].numpy())
+        assert np.array_equal(p["sum_swap_accept_count"], want["swap_accept_count"].numpy())
+        np.testing.assert_allclose(p["sum_esjd"], want["esjd"].numpy(), rtol=1e-12)
+        assert float(p["sum_swap_acceptance_rate"]) == want["swap_acceptance_rate"]
+
+
+def test_second_plan_with_large_lds_on_the_same_process(device):
+    """The raised dynamic-LDS allowance (> 48 KB: wide ladders at large dims) is set per device inside the library;
+    a process that has already run one such plan must be able to build and run a second, different one (and the
+    binding needs no torch.cuda.set_device from the caller)."""
+    for dim, T in ((100, 130), (64, 200), (100, 130)):
+        mean = torch.linspace(-1, 1, dim)
+        target = MultivariateNormalTorch(dim, mean=mean.tolist(), cov=torch.diag(torch.linspace(0.5, 2.0, dim)).tolist(),
+                                         device=device)
+        alg = ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target, beta_ladder=geometric_beta_ladder(T),
+                                                 swap_every=2, burn_in=0, device=device, num_replicas=3, seed=1, trace="none")
+        alg._advance(12)
+        torch.cuda.synchronize()
+        assert torch.isfinite(alg._run.state).all() and alg.num_swap_acceptances > 0
 
 
 def test_fused_step_helper_matches_kernel_rule(device):
