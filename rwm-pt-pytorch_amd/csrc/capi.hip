@@ -181,7 +181,9 @@ __global__ void __launch_bounds__(256) swap_sweep_kernel(const SweepArgs a) {
   __syncthreads();
   float *gs = a.state + chain * T * (long long)D;
   const float *prev = a.prev != nullptr ? a.prev + chain * T * (long long)D : nullptr;
-  float j2 = 0.0f;  // |final - prev|^2 of this thread's replica, accumulated in dimension order like the fused kernel
+  // |final - prev|^2 of this thread's replica in the canonical four-range order of the fused kernel (philox.h)
+  const int W = canon_width(D);
+  float j2p0 = 0.0f, j2p1 = 0.0f, j2p2 = 0.0f, j2p3 = 0.0f;
   for (int c0 = 0; c0 < D; c0 += a.chunk) {
     const int w = (D - c0 < a.chunk) ? D - c0 : a.chunk;
     for (int i = tid; i < T * w; i += nthr) {
@@ -196,7 +198,11 @@ __global__ void __launch_bounds__(256) swap_sweep_kernel(const SweepArgs a) {
     if (live && prev != nullptr) {
       for (int dd = 0; dd < w; ++dd) {
         const float dl = sub_rn(s_rows[src * w + dd], prev[t * D + c0 + dd]);
-        j2 = fmaf(dl, dl, j2);
+        const int qi = (c0 + dd) / W;
+        if (qi == 0) j2p0 = fmaf(dl, dl, j2p0);
+        else if (qi == 1) j2p1 = fmaf(dl, dl, j2p1);
+        else if (qi == 2) j2p2 = fmaf(dl, dl, j2p2);
+        else j2p3 = fmaf(dl, dl, j2p3);
       }
     }
     __syncthreads();
@@ -204,7 +210,7 @@ __global__ void __launch_bounds__(256) swap_sweep_kernel(const SweepArgs a) {
   if (live) {
     const long long rep = chain * T + t;
     a.logp[rep] = my_l;
-    if (a.sq_jump != nullptr) a.sq_jump[rep] += (double)j2;
+    if (a.sq_jump != nullptr) a.sq_jump[rep] += (double)add_rn(add_rn(j2p0, j2p1), add_rn(j2p2, j2p3));
     if (pair_acc) {
       if (a.swap_accept != nullptr) a.swap_accept[rep] += 1;
       if (a.last_swap_ordinal != nullptr) {
@@ -236,14 +242,21 @@ __global__ void __launch_bounds__(256) split_accept_kernel(const SplitAcceptArgs
   const bool acc = mh_accept(a.beta[t], lp_new, lp, a.accept_u[i]);
   float *__restrict__ x = a.state + i * a.dim;
   float *__restrict__ y = a.proposals + i * a.dim;
-  float j2 = 0.0f;
-  for (int d = 0; d < a.dim; ++d) {
-    const float xo = x[d], yn = y[d];
-    const float dl = sub_rn(yn, xo);
-    j2 = fmaf(dl, dl, j2);
-    if (acc) x[d] = yn;
-    y[d] = xo;
+  // squared jump in the canonical four-range order of the fused kernel (philox.h)
+  const int W = canon_width(a.dim);
+  float j2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int d1 = (q + 1) * W < a.dim ? (q + 1) * W : a.dim;
+    for (int d = q * W; d < d1; ++d) {
+      const float xo = x[d], yn = y[d];
+      const float dl = sub_rn(yn, xo);
+      j2p[q] = fmaf(dl, dl, j2p[q]);
+      if (acc) x[d] = yn;
+      y[d] = xo;
+    }
   }
+  const float j2 = tree4_add(j2p);
   if (acc) a.logp[i] = lp_new;
   if (a.accept_flags != nullptr) a.accept_flags[i] = acc ? 1 : 0;
   if (a.count_on) {

@@ -349,17 +349,20 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       if (a.full.accept_flags != nullptr && live) a.full.accept_flags[srep] = acc ? 1 : 0;
     }
 
-    float j2 = 0.0f;
+    float j2;
+    constexpr int W = canon_width(DP);
+    float j2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // squared jump in the canonical four-range order (philox.h)
     if (!swap_due) {
 #pragma unroll
       for (int d = 0; d < DP; ++d) {
         if (d < D) {
           const float dl = sub_rn(y[d], x[d]);
-          j2 = fmaf(dl, dl, j2);
+          j2p[d / W] = fmaf(dl, dl, j2p[d / W]);
           x[d] = acc ? y[d] : x[d];
         }
         if ((d & 7) == 7) sched_fence_soft();
       }
+      j2 = tree4_add(j2p);
       if (!acc) j2 = 0.0f;
       lp = lp_mh;
     } else {
@@ -412,11 +415,12 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
           if (d < Dr) {
             const float w = src_row[d];
             const float dl = sub_rn(w, x[d]);
-            j2 = fmaf(dl, dl, j2);
+            j2p[d / W] = fmaf(dl, dl, j2p[d / W]);
             x[d] = w;
           }
           if ((d & 7) == 7) sched_fence_soft();
         }
+        j2 = tree4_add(j2p);
       }
       lp = my_l;
       ++swap_in_call;

@@ -150,4 +150,18 @@ __device__ __forceinline__ float div_rn(float a, float b) {
   return a / b;
 }
 
+// ---- canonical reduction order -------------------------------------------------------------------------------
+// Every sum over the dimensions of a replica (log-density terms, squared jump, the UniformRadius norm) is taken in ONE
+// order, whatever kernel evaluates it: the dimensions are cut into FOUR contiguous ranges of canon_width() entries,
+// each range is a sequential chain starting from the identity, and the four partial results are combined pairwise,
+// (P0 + P1) + (P2 + P3).  The one-thread-per-replica kernel walks the four ranges itself; the lane-split kernel
+// (kernel_quad.h) gives one range to each of the four lanes of a replica and combines with two DPP quad permutes.
+// Same operations on the same operands in the same order => bit-identical results, so the choice of kernel (made by
+// the C ABI from the batch size) can never change a trajectory.  The width depends only on the register-width class,
+// which is a function of dim: dim <= 32 -> 8, dim <= 64 -> 16, dim <= 112 -> 28.
+constexpr int canon_width(int dp) { return dp <= 32 ? 8 : (dp <= 64 ? 16 : 28); }
+
+__device__ __forceinline__ float tree4_add(const float (&p)[4]) { return add_rn(add_rn(p[0], p[1]), add_rn(p[2], p[3])); }
+__device__ __forceinline__ float tree4_neg_add(const float (&p)[4]) { return -tree4_add(p); }
+
 }  // namespace ptrwm

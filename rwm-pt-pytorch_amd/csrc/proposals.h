@@ -189,11 +189,12 @@ struct UniformRadiusProposal {
       u_rad = ua;
       u_acc = ub;
     }
-    float n2 = 0.0f;
+    constexpr int W = canon_width(DP);
+    float n2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // |g|^2 in the canonical four-range order (philox.h)
 #pragma unroll
     for (int d = 0; d < DP; ++d)
-      if (d < D) n2 = fmaf(y[d], y[d], n2);
-    const float nrm = hw_sqrt(n2);
+      if (d < D) n2p[d / W] = fmaf(y[d], y[d], n2p[d / W]);
+    const float nrm = hw_sqrt(tree4_add(n2p));
     const float safe = nrm > 1e-12f ? nrm : 1.0f;
     const float rad = tscale * hw_exp2(pp.inv_dim * hw_log2(u_rad));
     // g / n as g * (1/n) with one IEEE reciprocal per step: <= 1.5 ulp from the reference's per-element division

@@ -31,7 +31,26 @@ constexpr float kNegInf = -__builtin_huge_valf();
 // expansion of the square, which would cancel catastrophically at the +-15
 // modes), sorted with max3/med3/min3 so only two v_exp_f32 are needed, and the
 // log of the 3-term sum is deferred: sum_d log2(s_d) = log2(prod_d s_d) with
-// s_d in [1,3], one v_log_f32 per 32 dimensions instead of one per dimension.
+// s_d in [1,3], two v_log_f32 per evaluation instead of one per dimension.  All
+// sums over dimensions run in the canonical four-range order (philox.h).
+// One dimension of the rough carpet from its three centred coordinates: mx = the largest exponent (log2 domain),
+// s = 1 + 2^(md - mx) (+ 2^(mn - mx)): the sum of the three terms relative to the largest.  Shared by both kernels.
+template <bool STRICT, bool TWO>
+__device__ __forceinline__ void rc_dim_term(float d0, float d1, float d2, float nh, float w0, float w1, float w2,
+                                            float &mx, float &s) {
+  const float a0 = fmaf(d0 * d0, nh, w0);
+  const float a1 = fmaf(d1 * d1, nh, w1);
+  const float a2 = fmaf(d2 * d2, nh, w2);
+  mx = __builtin_fmaxf(__builtin_fmaxf(a0, a1), a2);
+  const float md = __builtin_amdgcn_fmed3f(a0, a1, a2);
+  const float sh = STRICT ? __builtin_fmaxf(mx, -3.0e38f) : mx;
+  s = 1.0f + hw_exp2(md - sh);
+  if constexpr (!TWO) {
+    const float mn = __builtin_fminf(__builtin_fminf(a0, a1), a2);
+    s += hw_exp2(mn - sh);
+  }
+}
+
 template <int DP, bool TWO_TERM>
 struct RoughCarpetT {
   static constexpr int kKind = PTRWM_TARGET_ROUGH_CARPET;
@@ -49,7 +68,8 @@ struct RoughCarpetT {
     // log2-domain log-weights
     const float w0 = tp.p[3] * kLog2e, w1 = tp.p[4] * kLog2e, w2 = tp.p[5] * kLog2e;
     const float nh = -0.5f * kLog2e;
-    float sum_mx = 0.0f, prod = 1.0f, lg = 0.0f;
+    constexpr int W = canon_width(DP);
+    float sm[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pr[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // canonical four-range partials (philox.h)
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
       if (d < D) {
@@ -61,29 +81,19 @@ struct RoughCarpetT {
         } else {
           d0 = y[d] - m0, d1 = y[d] - m1, d2 = y[d] - m2;
         }
-        const float a0 = fmaf(d0 * d0, nh, w0);
-        const float a1 = fmaf(d1 * d1, nh, w1);
-        const float a2 = fmaf(d2 * d2, nh, w2);
-        const float mx = __builtin_fmaxf(__builtin_fmaxf(a0, a1), a2);
-        const float md = __builtin_amdgcn_fmed3f(a0, a1, a2);
-        const float sh = STRICT ? __builtin_fmaxf(mx, -3.0e38f) : mx;
-        float s = 1.0f + hw_exp2(md - sh);
-        if constexpr (!TWO) {
-          const float mn = __builtin_fminf(__builtin_fminf(a0, a1), a2);
-          s += hw_exp2(mn - sh);
-        }
-        sum_mx += mx;
-        prod *= s;
+        float mx, s;
+        rc_dim_term<STRICT, TWO>(d0, d1, d2, nh, w0, w1, w2, mx, s);
+        sm[d / W] = add_rn(sm[d / W], mx);
+        pr[d / W] = mul_rn(pr[d / W], s);
       }
       if ((d & 3) == 3) sched_fence_soft();
-      if ((d & 31) == 31 && d + 1 < DP) {
-        lg += hw_log2(prod);
-        prod = 1.0f;
-      }
     }
-    lg += hw_log2(prod);
+    const float sum_mx = tree4_add(sm);
+    // each factor is in [1, 3] and a range holds at most 28 of them: the product of two ranges (<= 3^56) cannot
+    // overflow, the product of all four could (3^112), so the log is taken per pair of ranges
+    const float lg = add_rn(hw_log2(mul_rn(pr[0], pr[1])), hw_log2(mul_rn(pr[2], pr[3])));
     // p[6] = log_jacobian, p[7] = -dim * log(sqrt(2 pi)) folded on the host
-    return fmaf(sum_mx + lg, kLn2, tp.p[7]) + tp.p[6];
+    return add_rn(fmaf(add_rn(sum_mx, lg), kLn2, tp.p[7]), tp.p[6]);
   }
   template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
@@ -105,7 +115,8 @@ struct ThreeMixture {
   static constexpr int kKind = PTRWM_TARGET_THREE_MIXTURE;
   template <bool SCALED>
   __device__ __forceinline__ static float logp_impl(const float (&y)[DP], int D, const TParams &tp) {
-    float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
+    constexpr int W = canon_width(DP);
+    float q0p[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q1p[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const const_float_ptr uv0 = uniform_vec(tp.vec0);
     [[maybe_unused]] const const_float_ptr uv1 = SCALED ? uniform_vec(tp.vec1) : nullptr;
 #pragma unroll
@@ -116,21 +127,27 @@ struct ThreeMixture {
           const float sc = uv1[d];  // s x - mu_k as one explicit fma each, the same in every kernel
           e0 = fmaf(y[d], sc, -uv0[d]), e1 = fmaf(y[d], sc, -uv0[D + d]), e2 = fmaf(y[d], sc, -uv0[2 * D + d]);
         } else {
-          e0 = y[d] - uv0[d], e1 = y[d] - uv0[D + d], e2 = y[d] - uv0[2 * D + d];
+          e0 = sub_rn(y[d], uv0[d]), e1 = sub_rn(y[d], uv0[D + d]), e2 = sub_rn(y[d], uv0[2 * D + d]);
         }
-        q0 = fmaf(e0, e0, q0);
-        q1 = fmaf(e1, e1, q1);
-        q2 = fmaf(e2, e2, q2);
+        q0p[d / W] = fmaf(e0, e0, q0p[d / W]);
+        q1p[d / W] = fmaf(e1, e1, q1p[d / W]);
+        q2p[d / W] = fmaf(e2, e2, q2p[d / W]);
       }
       if ((d & 7) == 7) sched_fence_soft();
     }
+    const float q0 = tree4_add(q0p), q1 = tree4_add(q1p), q2 = tree4_add(q2p);
+    return finish(q0, q1, q2, tp);
+  }
+  // logsumexp of the three components from their squared distances (shared with the lane-split kernel)
+  __device__ __forceinline__ static float finish(float q0, float q1, float q2, const TParams &tp) {
+#pragma clang fp contract(off)
     const float a0 = fmaf(-0.5f, q0, tp.p[0]);
     const float a1 = fmaf(-0.5f, q1, tp.p[1]);
     const float a2 = fmaf(-0.5f, q2, tp.p[2]);
     const float mx = __builtin_fmaxf(__builtin_fmaxf(a0, a1), a2);
     const float sh = __builtin_fmaxf(mx, -3.0e38f);  // all components -inf -> -inf like torch.logsumexp, not NaN
-    const float s = hw_exp((a0 - sh)) + hw_exp((a1 - sh)) + hw_exp((a2 - sh));
-    return mx + hw_ln(s);
+    const float s = (hw_exp(a0 - sh) + hw_exp(a1 - sh)) + hw_exp(a2 - sh);
+    return fmaf(hw_log2(s), kLn2, mx);  // ONE explicit fma in every kernel (left to the optimiser it differed)
   }
   template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
@@ -147,19 +164,20 @@ struct FullRosenbrock {
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
 #pragma clang fp contract(off)
     const float a = tp.p[0], b = tp.p[1];
-    float s1 = 0.0f, s2 = 0.0f;
+    constexpr int W = canon_width(DP);
+    float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // term i belongs to the range of dim i
     const const_float_ptr uv0 = uniform_vec(tp.vec0);
 #pragma unroll
     for (int i = 0; i + 1 < DP; ++i) {
       if (i + 1 < D) {
         const float r = y[i + 1] - y[i] * y[i];
         const float c = y[i] - uv0[i];
-        s1 = fmaf(b * r, r, s1);
-        s2 = fmaf(a * c, c, s2);
+        s1[i / W] = fmaf(b * r, r, s1[i / W]);
+        s2[i / W] = fmaf(a * c, c, s2[i / W]);
       }
       if ((i & 7) == 7) sched_fence_soft();
     }
-    return -(s1 + s2);
+    return -(tree4_add(s1) + tree4_add(s2));
   }
 };
 
@@ -172,19 +190,20 @@ struct EvenRosenbrock {
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
 #pragma clang fp contract(off)
     const float a = tp.p[0], b = tp.p[1];
-    float s1 = 0.0f, s2 = 0.0f;
+    constexpr int W = canon_width(DP);  // even: a pair (2i, 2i+1) never straddles two ranges
+    float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const const_float_ptr uv0 = uniform_vec(tp.vec0);
 #pragma unroll
     for (int i = 0; 2 * i + 1 < DP; ++i) {
       if (2 * i + 1 < D) {
         const float c = y[2 * i] - uv0[i];
         const float r = y[2 * i + 1] - y[2 * i] * y[2 * i];
-        s1 = fmaf(a * c, c, s1);
-        s2 = fmaf(b * r, r, s2);
+        s1[(2 * i) / W] = fmaf(a * c, c, s1[(2 * i) / W]);
+        s2[(2 * i) / W] = fmaf(b * r, r, s2[(2 * i) / W]);
       }
       if ((i & 3) == 3) sched_fence_soft();
     }
-    return -(s1 + s2);
+    return -(tree4_add(s1) + tree4_add(s2));
   }
 };
 
@@ -200,7 +219,8 @@ struct HybridRosenbrock {
 #pragma clang fp contract(off)
     const float a = tp.p[0], b = tp.p[1], mu = tp.p[2];
     const float c0 = y[0] - mu;
-    float acc = a * c0 * c0;
+    constexpr int W = canon_width(DP);
+    float acc[4] = {a * c0 * c0, 0.0f, 0.0f, 0.0f};  // the x_0 term opens the chain of the first range
 #pragma unroll
     for (int i = 1; i < DP; ++i) {
       if (i < D) {
@@ -212,11 +232,11 @@ struct HybridRosenbrock {
         asm volatile("" : "+v"(prev));
         const float parent = head ? y[0] : prev;
         const float r = y[i] - parent * parent;
-        acc = fmaf(b * r, r, acc);
+        acc[i / W] = fmaf(b * r, r, acc[i / W]);
       }
       if ((i & 7) == 7) sched_fence_soft();
     }
-    return -acc;
+    return -tree4_add(acc);
   }
 };
 
@@ -230,18 +250,19 @@ struct IIDGamma {
 #pragma clang fp contract(off)
     const float km1 = (tp.p[0] - 1.0f) * kLn2;
     const float inv_theta = 1.0f / tp.p[1];
-    float acc = 0.0f;
+    constexpr int W = canon_width(DP);
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     bool bad = false;
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
       if (d < D) {
         const float v = y[d];
         bad = bad || (v <= 0.0f);
-        acc += fmaf(km1, hw_log2(v), -(v * inv_theta));
+        acc[d / W] += fmaf(km1, hw_log2(v), -(v * inv_theta));
       }
       if ((d & 7) == 7) sched_fence_soft();
     }
-    return bad ? kNegInf : acc - tp.p[2];
+    return bad ? kNegInf : tree4_add(acc) - tp.p[2];
   }
 };
 
@@ -255,18 +276,19 @@ struct IIDBeta {
 #pragma clang fp contract(off)
     const float am1 = (tp.p[0] - 1.0f) * kLn2;
     const float bm1 = (tp.p[1] - 1.0f) * kLn2;
-    float acc = 0.0f;
+    constexpr int W = canon_width(DP);
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     bool bad = false;
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
       if (d < D) {
         const float v = y[d];
         bad = bad || (v <= 0.0f) || (v >= 1.0f);
-        acc += fmaf(am1, hw_log2(v), bm1 * hw_log2(1.0f - v));
+        acc[d / W] += fmaf(am1, hw_log2(v), bm1 * hw_log2(1.0f - v));
       }
       if ((d & 7) == 7) sched_fence_soft();
     }
-    return bad ? kNegInf : acc + tp.p[2];
+    return bad ? kNegInf : tree4_add(acc) + tp.p[2];
   }
 };
 
@@ -278,7 +300,8 @@ struct DiagGaussian {
   template <bool SCALED_FORM>
   __device__ __forceinline__ static float quad(const float (&y)[DP], int D, const TParams &tp) {
 #pragma clang fp contract(off)
-    float q = 0.0f;
+    constexpr int W = canon_width(DP);
+    float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const const_float_ptr uv0 = uniform_vec(tp.vec0);
     [[maybe_unused]] const const_float_ptr uv1 = SCALED_FORM ? nullptr : uniform_vec(tp.vec1);
 #pragma unroll
@@ -286,15 +309,15 @@ struct DiagGaussian {
       if (d < D) {
         if constexpr (SCALED_FORM) {
           const float sx = uv0[d] * y[d];
-          q = fmaf(sx, sx, q);
+          q[d / W] = fmaf(sx, sx, q[d / W]);
         } else {
           const float c = y[d] - uv0[d];
-          q = fmaf(c * uv1[d], c, q);
+          q[d / W] = fmaf(c * uv1[d], c, q[d / W]);
         }
       }
       if ((d & 7) == 7) sched_fence_soft();
     }
-    return q;
+    return tree4_add(q);
   }
   template <bool STRICT = false>
   __device__ __forceinline__ static float logp(const float (&y)[DP], int D, const TParams &tp) {
@@ -333,15 +356,17 @@ struct NealFunnel {
     const float v = y[0];
     const float dv = v - mu_v;
     const float prior = -0.5f * log_2pi - 0.5f * (hw_log2(s2) * kLn2) - 0.5f * (dv * dv) / s2;
-    float ss = 0.0f;
+    constexpr int W = canon_width(DP);
+    float ssp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int d = 1; d < DP; ++d) {
       if (d < D) {
         const float c = y[d] - mu_z;
-        ss = fmaf(c, c, ss);
+        ssp[d / W] = fmaf(c, c, ssp[d / W]);
       }
       if ((d & 7) == 7) sched_fence_soft();
     }
+    const float ss = tree4_add(ssp);
     const float dm1 = (float)(D - 1);
     const float lik = -0.5f * dm1 * log_2pi - 0.5f * dm1 * v - 0.5f * hw_exp(-v) * ss;
     return D > 1 ? prior + lik : prior;
