@@ -17,6 +17,36 @@ struct VariantPair {
   }
 };
 
+// ---- which form of the step kernel runs (quad.h) ------------------------------------------------------------------
+// The two forms are bit-identical on the same Philox stream, so this is a speed decision only; ptrwm_set_kernel_form()
+// pins it for tests and tuning.  AUTO follows the measured crossover (profiles/r02_form_sweep.txt, both forms timed over
+// batch sizes, ladder lengths and dims on one MI355X).  w = wavefronts per SIMD the one-thread-per-replica kernel would
+// launch:
+//   dim <= 32        lane-split when w < 1.6 (ladders of <= 16 temperatures) or w < 1.0 (longer ladders): a lone wave
+//                    issues one VALU instruction per ~5 cycles instead of ~3.4, and below one wave per SIMD the split
+//                    puts four times as many SIMDs to work (2.5-3.2x for a single ladder)
+//   32 < dim <= 64   the four lanes own 16 dims each, so dims well below 64 waste lanes (dim 50: 28 %): lane-split when
+//                    w < 0.75, or always for dim >= 60 (there the thread kernel is held to two waves per SIMD)
+//   dim > 64         the thread kernel's register arrays allow one wave per SIMD: lane-split for ladders of <= 64
+//                    temperatures (1.04-1.25x at full batches, 1.8x at small ones)
+static int g_kernel_form = PTRWM_FORM_AUTO;
+constexpr long long kSimds = 1024;  // 256 CUs x 4
+
+static const QuadVariants &quad_variants(int kind, bool two_term) {
+  switch (kind) {
+    case PTRWM_TARGET_ROUGH_CARPET: return two_term ? rough_carpet2_variants_quad() : rough_carpet_variants_quad();
+    case PTRWM_TARGET_THREE_MIXTURE: return three_mixture_variants_quad();
+    case PTRWM_TARGET_FULL_ROSENBROCK: return full_rosenbrock_variants_quad();
+    case PTRWM_TARGET_EVEN_ROSENBROCK: return even_rosenbrock_variants_quad();
+    case PTRWM_TARGET_HYBRID_ROSENBROCK: return hybrid_rosenbrock_variants_quad();
+    case PTRWM_TARGET_IID_GAMMA: return iid_gamma_variants_quad();
+    case PTRWM_TARGET_IID_BETA: return iid_beta_variants_quad();
+    case PTRWM_TARGET_DIAG_GAUSSIAN: return diag_gaussian_variants_quad();
+    case PTRWM_TARGET_HYPERCUBE: return hypercube_variants_quad();
+    default: return neal_funnel_variants_quad();
+  }
+}
+
 static VariantPair target_variants(int kind, bool two_term = false) {
 #define PTRWM_PAIR(SYMBOL) VariantPair{&SYMBOL##_narrow(), &SYMBOL##_wide()}
   switch (kind) {
@@ -349,6 +379,21 @@ const char *ptrwm_strerror(int32_t code) {
   }
 }
 
+int32_t ptrwm_set_kernel_form(int32_t form) {
+  if (form != PTRWM_FORM_AUTO && form != PTRWM_FORM_THREAD && form != PTRWM_FORM_QUAD) return PTRWM_E_ARG;
+  const int32_t prev = g_kernel_form;
+  g_kernel_form = form;
+  return prev;
+}
+
+int32_t ptrwm_has_quad_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim, int32_t n_temps) {
+  if (target_kind < 0 || target_kind >= PTRWM_TARGET_COUNT) return 0;
+  if (proposal_kind < 0 || proposal_kind >= PTRWM_PROPOSAL_COUNT) return 0;
+  const int qi = quad_index_for_dim(dim);
+  if (qi < 0 || n_temps < 1 || n_temps > kQuadMaxTemps) return 0;
+  return quad_variants(target_kind, false).run[proposal_kind][qi] != nullptr ? 1 : 0;
+}
+
 int32_t ptrwm_ext_raw_per_step(int32_t proposal_kind, int32_t dim) {
   switch (proposal_kind) {
     case PTRWM_PROPOSAL_NORMAL: return dim;
@@ -391,8 +436,30 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   const int dpi = width_index_for_dim(target->dim);
   if (dpi < 0) return PTRWM_E_DIM;
   const bool two_term = target->kind == PTRWM_TARGET_ROUGH_CARPET && rough_carpet_two_term(target->p);
-  const RunLaunchFn fn = target_variants(target->kind, two_term).run(proposal->kind, dpi);
+  RunLaunchFn fn = target_variants(target->kind, two_term).run(proposal->kind, dpi);
   if (fn == nullptr) return PTRWM_E_NOVARIANT;
+  // lane-split form? (bit-identical results: a speed decision, see g_kernel_form)
+  bool quad = false;
+  {
+    const int qi = quad_index_for_dim(target->dim);
+    const RunLaunchFn qfn = (qi >= 0 && args->n_temps <= kQuadMaxTemps)
+                                ? quad_variants(target->kind, two_term).run[proposal->kind][qi] : nullptr;
+    if (qfn != nullptr && g_kernel_form != PTRWM_FORM_THREAD) {
+      const long long cpw1 = args->n_temps > 64 ? 1 : 64 / args->n_temps;
+      const long long waves1 = args->n_temps > 64 ? args->n_chains * ((args->n_temps + 63) / 64)
+                                                  : (args->n_chains + cpw1 - 1) / cpw1;
+      const double w = (double)waves1 / (double)kSimds;
+      bool faster;
+      if (target->dim <= 32)
+        faster = args->n_temps <= 16 ? w < 1.6 : w < 1.0;
+      else if (target->dim <= 64)
+        faster = w < 0.75 || (target->dim >= 60 && args->n_temps <= 64);
+      else
+        faster = args->n_temps <= 64;
+      quad = g_kernel_form == PTRWM_FORM_QUAD || faster;
+      if (quad) fn = qfn;
+    }
+  }
 
   const long long se = args->swap_every;
   const bool full = ext || args->trace != nullptr || args->accept_flags != nullptr;
@@ -421,8 +488,10 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   k.swap_every = args->swap_every;
   k.swap_mode = args->swap_mode;
   k.swap_order = args->swap_order;
-  const bool wide = args->n_temps > 64;  // one ladder per 256-thread workgroup
-  k.chains_per_wave = wide ? 1 : 64 / args->n_temps;
+  // exchange groups: one wavefront holding whole ladders, or ("wide") one workgroup per ladder
+  const int lanes_per_replica = quad ? kQuad : 1;
+  const bool wide = args->n_temps * lanes_per_replica > 64;
+  k.chains_per_wave = wide ? 1 : 64 / (args->n_temps * lanes_per_replica);
   k.k0 = (unsigned)(args->seed & 0xffffffffull);
   k.k1 = (unsigned)(args->seed >> 32);
   k.tp = make_tparams(target);

@@ -1,0 +1,722 @@
+// The lane-split ("quad") form of the fused PT-RWM kernel: FOUR lanes per (chain, temperature) replica.
+//
+// Why: the one-thread-per-replica kernel (kernel.h) needs >= 2 wavefronts per SIMD to keep the VALU issuing
+// (profiles/r02_pmc_cfg2.csv: BASELINE configs[1], 65 536 chains x 1 temperature = ONE wave per SIMD, issues at 0.41 of
+// the peak against 0.59 at four waves), and above dim 64 its register arrays (x[], y[]: 2 x dim VGPRs) leave room for
+// one wave per SIMD only.  Here lane q of a quad owns the dimensions [q W, (q+1) W) of its replica (W = canon_width:
+// 8 / 16 / 28 for dim <= 32 / 64 / 112): a quarter of the Philox blocks, of the proposal transforms and of the
+// log-density terms, 2 W registers for the state, four times the waves for the same batch.
+//
+// Bit-identical to kernel.h by construction: same Philox words (word w of a step is word w whoever computes it), same
+// per-dimension arithmetic, and every sum over dimensions in the canonical four-range order of philox.h - each lane
+// runs the chain of its own range, two DPP quad permutes combine them as (P0 + P1) + (P2 + P3).  All four lanes then
+// hold the same log-density, make the same Metropolis and swap decisions and update their own quarter of the state.
+// The C ABI picks the form from the batch size and dim (capi.hip); tools/check_all_variants.py checks every variant of
+// this kernel against kernel.h on the same Philox stream, bit for bit.
+//
+// Thread map.  slot = tid / 4 (replica within the exchange group), q = tid % 4.  4 T <= 64 ("narrow", T <= 16): an
+// exchange group is one wavefront holding 16 / T whole ladders; a workgroup is four independent wavefronts.
+// 16 < T <= 128 ("wide"): one ladder per workgroup of 4 T threads (rounded up to whole waves, <= 512), barriers for swaps.
+#pragma once
+#include "kernel.h"
+
+namespace ptrwm {
+
+constexpr int kQuad = 4;
+
+// ---- DPP quad permutes (lane i of a quad reads lane SEL_i; full rate, no LDS) --------------------------------------
+constexpr int quad_ctrl(int s0, int s1, int s2, int s3) { return s0 | (s1 << 2) | (s2 << 4) | (s3 << 6); }
+constexpr int kDppSwapPair = quad_ctrl(1, 0, 3, 2);   // partner inside the pair
+constexpr int kDppSwapHalf = quad_ctrl(2, 3, 0, 1);   // the other pair
+constexpr int kDppNext = quad_ctrl(1, 2, 3, 3);       // lane q reads lane q + 1 (lane 3: itself)
+constexpr int kDppPrev = quad_ctrl(0, 0, 1, 2);       // lane q reads lane q - 1 (lane 0: itself)
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int LANE>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return dpp_f<quad_ctrl(LANE, LANE, LANE, LANE)>(v);
+}
+// (P0 + P1) + (P2 + P3) on every lane: the canonical combination of philox.h (fp add is commutative bit for bit)
+__device__ __forceinline__ float quad_tree_add(float p) {
+  const float t = add_rn(p, dpp_f<kDppSwapPair>(p));
+  return add_rn(t, dpp_f<kDppSwapHalf>(t));
+}
+__device__ __forceinline__ bool quad_any(bool b) {
+  int v = b ? 1 : 0;
+  v |= dpp_i<kDppSwapPair>(v);
+  v |= dpp_i<kDppSwapHalf>(v);
+  return v != 0;
+}
+
+// What a lane knows about its share of the replica
+struct QLane {
+  int q;      // lane within the quad
+  int n_own;  // owned dimensions: clamp(D - q W, 0, W)
+  int d0;     // first owned dimension, q W
+};
+
+// valid(j): does local slot j hold a dimension?  MIN_OWN (a compile-time lower bound of n_own over the four lanes, known
+// when dim is compiled in) lets the compiler drop the test for the slots every lane owns.
+template <int MIN_OWN>
+__device__ __forceinline__ bool q_valid(const QLane &l, int j) {
+  return j < MIN_OWN || j < l.n_own;
+}
+
+// ---- proposals ---------------------------------------------------------------------------------------------------------
+// Same raw-word map as proposals.h: local Philox block b of lane q is global block q W/4 + b, i.e. dims 4c .. 4c+3.
+// Every lane of the wave executes every block anyway, so a block is computed when ANY lane needs it (a wave-uniform
+// test); the accept (and radius) words are picked up by the lane whose block holds them and shared through the quad.
+template <int W, int MIN_OWN>
+struct QNormal {
+  static constexpr int kKind = PTRWM_PROPOSAL_NORMAL;
+  __device__ __forceinline__ static float propose(float (&y)[W], const float (&x)[W], const QLane &l, int D, float tscale,
+                                                  const PParams &, const RngCtx &rc, const float *ext_rep, float ext_u) {
+    if (ext_rep != nullptr) {
+      const float *er = ext_rep + l.d0;
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+        if (q_valid<MIN_OWN>(l, j)) y[j] = add_rn(x[j], mul_rn(er[j], tscale));
+      return ext_u;
+    }
+    const int w_a = 2 * ((D + 1) >> 1);  // accept word
+    const int c_a = w_a >> 2;            // its block (uniform)
+    const uint32_t cb0 = (uint32_t)(l.q * (W / 4));
+    float u_loc = 0.0f;
+#pragma unroll
+    for (int b = 0; b < W / 4; ++b) {
+      if (4 * b < D || (c_a < W && (c_a % (W / 4)) == b)) {  // wave-uniform: lane 0 has dims there, or the accept word is
+        const uint32_t cb = cb0 + (uint32_t)b;
+        const u32x4 r = philox4x32_10(rc.c0hi | cb, rc.c1, rc.c2, rc.c3, rc.k0, rc.k1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = 4 * b + 2 * h;
+          const uint32_t ra = h ? r.z : r.x, rb = h ? r.w : r.y;
+          if (q_valid<MIN_OWN>(l, j)) {
+            const float rad = tscale * hw_sqrt(bm_radius_sq(ra));
+            const float ang = bm_turns(rb);
+            y[j] = fmaf(rad, __builtin_amdgcn_sinf(ang), x[j]);
+            if (q_valid<MIN_OWN>(l, j + 1)) y[j + 1] = fmaf(rad, __builtin_amdgcn_cosf(ang), x[j + 1]);
+          }
+          if ((int)(4 * cb) + 2 * h == w_a) u_loc = u01(ra);
+        }
+        sched_fence();
+      }
+    }
+    if (c_a >= W) {  // dim = 4 W or 4 W - 1: the accept word opens block W, which no lane owns: all compute it
+      const u32x4 r = philox4x32_10(rc.c0hi | (uint32_t)W, rc.c1, rc.c2, rc.c3, rc.k0, rc.k1);
+      return u01(r.x);
+    }
+    return quad_tree_add(u_loc);  // exact: three of the four terms are zero
+  }
+};
+
+template <int W, int MIN_OWN>
+struct QLaplace {
+  static constexpr int kKind = PTRWM_PROPOSAL_LAPLACE;
+  __device__ __forceinline__ static float propose(float (&y)[W], const float (&x)[W], const QLane &l, int D, float tscale,
+                                                  const PParams &pp, const RngCtx &rc, const float *ext_rep, float ext_u) {
+    const float *dsc = pp.dim_scale + l.d0;  // this lane's per-dimension scales (L1-resident; lane-dependent address)
+    if (ext_rep != nullptr) {
+      const float *er = ext_rep + l.d0;
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+        if (q_valid<MIN_OWN>(l, j)) y[j] = add_rn(x[j], LaplaceProposal<W>::transform(er[j], mul_rn(dsc[j], tscale)));
+      return ext_u;
+    }
+    const int c_a = D >> 2;  // block of the accept word (word D)
+    const uint32_t cb0 = (uint32_t)(l.q * (W / 4));
+    float u_loc = 0.0f;
+#pragma unroll
+    for (int b = 0; b < W / 4; ++b) {
+      if (4 * b < D || (c_a < W && (c_a % (W / 4)) == b)) {
+        const uint32_t cb = cb0 + (uint32_t)b;
+        const u32x4 r = philox4x32_10(rc.c0hi | cb, rc.c1, rc.c2, rc.c3, rc.k0, rc.k1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int j = 4 * b + k;
+          if (q_valid<MIN_OWN>(l, j)) y[j] = add_rn(x[j], LaplaceProposal<W>::transform(u01(pick(r, k)), mul_rn(dsc[j], tscale)));
+          if ((int)(4 * cb) + k == D) u_loc = u01(pick(r, k));
+        }
+        sched_fence();
+      }
+    }
+    if (c_a >= W) {
+      const u32x4 r = philox4x32_10(rc.c0hi | (uint32_t)W, rc.c1, rc.c2, rc.c3, rc.k0, rc.k1);
+      return u01(r.x);
+    }
+    return quad_tree_add(u_loc);
+  }
+};
+
+template <int W, int MIN_OWN>
+struct QUniformRadius {
+  static constexpr int kKind = PTRWM_PROPOSAL_UNIFORM_RADIUS;
+  __device__ __forceinline__ static float propose(float (&y)[W], const float (&x)[W], const QLane &l, int D, float tscale,
+                                                  const PParams &pp, const RngCtx &rc, const float *ext_rep, float ext_u) {
+    float u_acc = ext_u, u_rad;
+    if (ext_rep != nullptr) {
+      const float *er = ext_rep + l.d0;
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+        if (q_valid<MIN_OWN>(l, j)) y[j] = er[j];
+      u_rad = ext_rep[D];
+    } else {
+      const int w_a = 2 * ((D + 1) >> 1);  // radius word; the accept word is the next one (same block: w_a is even)
+      const int c_a = w_a >> 2;
+      const uint32_t cb0 = (uint32_t)(l.q * (W / 4));
+      float ur_loc = 0.0f, ua_loc = 0.0f;
+#pragma unroll
+      for (int b = 0; b < W / 4; ++b) {
+        if (4 * b < D || (c_a < W && (c_a % (W / 4)) == b)) {
+          const uint32_t cb = cb0 + (uint32_t)b;
+          const u32x4 r = philox4x32_10(rc.c0hi | cb, rc.c1, rc.c2, rc.c3, rc.k0, rc.k1);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int j = 4 * b + 2 * h;
+            const uint32_t ra = h ? r.z : r.x, rb = h ? r.w : r.y;
+            if (q_valid<MIN_OWN>(l, j)) {
+              float z0, z1;
+              box_muller(ra, rb, z0, z1);
+              y[j] = z0;
+              if (q_valid<MIN_OWN>(l, j + 1)) y[j + 1] = z1;
+            }
+            if ((int)(4 * cb) + 2 * h == w_a) {
+              ur_loc = u01(ra);
+              ua_loc = u01(rb);
+            }
+          }
+          sched_fence();
+        }
+      }
+      if (c_a >= W) {
+        const u32x4 r = philox4x32_10(rc.c0hi | (uint32_t)W, rc.c1, rc.c2, rc.c3, rc.k0, rc.k1);
+        u_rad = u01(r.x);
+        u_acc = u01(r.y);
+      } else {
+        u_rad = quad_tree_add(ur_loc);
+        u_acc = quad_tree_add(ua_loc);
+      }
+    }
+    float n2 = 0.0f;  // this lane's range of |g|^2, then the canonical combination
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+      if (q_valid<MIN_OWN>(l, j)) n2 = fmaf(y[j], y[j], n2);
+    const float nrm = hw_sqrt(quad_tree_add(n2));
+    const float safe = nrm > 1e-12f ? nrm : 1.0f;
+    const float rad = tscale * hw_exp2(pp.inv_dim * hw_log2(u_rad));
+    const float inv = div_rn(1.0f, safe);
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+      if (q_valid<MIN_OWN>(l, j)) y[j] = add_rn(x[j], mul_rn(mul_rn(y[j], inv), rad));
+    return u_acc;
+  }
+};
+
+// ---- targets ---------------------------------------------------------------------------------------------------------
+// logp(y_local, lane, D, params) -> the replica's log-density, the same bits on all four lanes.  Each functor restates
+// the per-dimension arithmetic of its twin in targets.h on the lane's own range and combines canonically.
+template <int W, int MIN_OWN, bool TWO_TERM>
+struct QRoughCarpetT {
+  static constexpr int kKind = PTRWM_TARGET_ROUGH_CARPET;
+  template <bool SCALED>
+  __device__ __forceinline__ static float impl(const float (&y)[W], const QLane &l, const TParams &tp) {
+    const float m0 = tp.p[0], m1 = tp.p[1], m2 = tp.p[2];
+    [[maybe_unused]] const float *sc_v = SCALED ? tp.vec0 + l.d0 : nullptr;
+    const float w0 = tp.p[3] * kLog2e, w1 = tp.p[4] * kLog2e, w2 = tp.p[5] * kLog2e;
+    const float nh = -0.5f * kLog2e;
+    float sm = 0.0f, pr = 1.0f;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      if (q_valid<MIN_OWN>(l, j)) {
+        float d0, d1, d2;
+        if constexpr (SCALED) {
+          const float sc = sc_v[j];
+          d0 = fmaf(y[j], sc, -m0), d1 = fmaf(y[j], sc, -m1), d2 = fmaf(y[j], sc, -m2);
+        } else {
+          d0 = y[j] - m0, d1 = y[j] - m1, d2 = y[j] - m2;
+        }
+        float mx, s;
+        rc_dim_term<false, TWO_TERM>(d0, d1, d2, nh, w0, w1, w2, mx, s);
+        sm = add_rn(sm, mx);
+        pr = mul_rn(pr, s);
+      }
+      if ((j & 3) == 3) sched_fence_soft();
+    }
+    const float sum_mx = quad_tree_add(sm);
+    const float lgp = hw_log2(mul_rn(pr, dpp_f<kDppSwapPair>(pr)));  // log2 of the pair's product (see targets.h)
+    const float lg = add_rn(lgp, dpp_f<kDppSwapHalf>(lgp));
+    return add_rn(fmaf(add_rn(sum_mx, lg), kLn2, tp.p[7]), tp.p[6]);
+  }
+  __device__ __forceinline__ static float logp(const float (&y)[W], const QLane &l, int, const TParams &tp) {
+    return tp.vec0 != nullptr ? impl<true>(y, l, tp) : impl<false>(y, l, tp);
+  }
+};
+template <int W, int MIN_OWN>
+using QRoughCarpet = QRoughCarpetT<W, MIN_OWN, false>;
+template <int W, int MIN_OWN>
+using QRoughCarpet2 = QRoughCarpetT<W, MIN_OWN, true>;
+
+template <int W, int MIN_OWN>
+struct QThreeMixture {
+  static constexpr int kKind = PTRWM_TARGET_THREE_MIXTURE;
+  template <bool SCALED>
+  __device__ __forceinline__ static float impl(const float (&y)[W], const QLane &l, int D, const TParams &tp) {
+    const float *mu = tp.vec0 + l.d0;
+    [[maybe_unused]] const float *sc_v = SCALED ? tp.vec1 + l.d0 : nullptr;
+    float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      if (q_valid<MIN_OWN>(l, j)) {
+        float e0, e1, e2;
+        if constexpr (SCALED) {
+          const float sc = sc_v[j];
+          e0 = fmaf(y[j], sc, -mu[j]), e1 = fmaf(y[j], sc, -mu[D + j]), e2 = fmaf(y[j], sc, -mu[2 * D + j]);
+        } else {
+          e0 = sub_rn(y[j], mu[j]), e1 = sub_rn(y[j], mu[D + j]), e2 = sub_rn(y[j], mu[2 * D + j]);
+        }
+        q0 = fmaf(e0, e0, q0);
+        q1 = fmaf(e1, e1, q1);
+        q2 = fmaf(e2, e2, q2);
+      }
+      if ((j & 7) == 7) sched_fence_soft();
+    }
+    return ThreeMixture<W>::finish(quad_tree_add(q0), quad_tree_add(q1), quad_tree_add(q2), tp);
+  }
+  __device__ __forceinline__ static float logp(const float (&y)[W], const QLane &l, int D, const TParams &tp) {
+    return tp.vec1 != nullptr ? impl<true>(y, l, D, tp) : impl<false>(y, l, D, tp);
+  }
+};
+
+template <int W, int MIN_OWN>
+struct QFullRosenbrock {
+  static constexpr int kKind = PTRWM_TARGET_FULL_ROSENBROCK;
+  __device__ __forceinline__ static float logp(const float (&y)[W], const QLane &l, int D, const TParams &tp) {
+#pragma clang fp contract(off)
+    const float a = tp.p[0], b = tp.p[1];
+    const float *mu = tp.vec0 + l.d0;
+    const float halo = dpp_f<kDppNext>(y[0]);  // x_{i+1} of this lane's last term lives in the next lane
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      if (l.d0 + j + 1 < D) {  // term i = d0 + j exists (then slot j is owned)
+        const float nxt = (j + 1 < W) ? y[j + 1 < W ? j + 1 : 0] : halo;
+        const float r = nxt - y[j] * y[j];
+        const float c = y[j] - mu[j];
+        s1 = fmaf(b * r, r, s1);
+        s2 = fmaf(a * c, c, s2);
+      }
+      if ((j & 7) == 7) sched_fence_soft();
+    }
+    return -(quad_tree_add(s1) + quad_tree_add(s2));
+  }
+};
+
+template <int W, int MIN_OWN>
+struct QEvenRosenbrock {
+  static constexpr int kKind = PTRWM_TARGET_EVEN_ROSENBROCK;
+  __device__ __forceinline__ static float logp(const float (&y)[W], const QLane &l, int D, const TParams &tp) {
+#pragma clang fp contract(off)
+    const float a = tp.p[0], b = tp.p[1];
+    const float *mu = tp.vec0 + (l.d0 >> 1);  // one mu per pair; W is a multiple of 4, so pairs never straddle lanes
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int i = 0; 2 * i + 1 < W; ++i) {
+      if (l.d0 + 2 * i + 1 < D) {
+        const float c = y[2 * i] - mu[i];
+        const float r = y[2 * i + 1] - y[2 * i] * y[2 * i];
+        s1 = fmaf(a * c, c, s1);
+        s2 = fmaf(b * r, r, s2);
+      }
+      if ((i & 3) == 3) sched_fence_soft();
+    }
+    return -(quad_tree_add(s1) + quad_tree_add(s2));
+  }
+};
+
+template <int W, int MIN_OWN>
+struct QHybridRosenbrock {
+  static constexpr int kKind = PTRWM_TARGET_HYBRID_ROSENBROCK;
+  __device__ __forceinline__ static float logp(const float (&y)[W], const QLane &l, int D, const TParams &tp) {
+#pragma clang fp contract(off)
+    const float a = tp.p[0], b = tp.p[1], mu = tp.p[2];
+    const float y0 = quad_bcast<0>(y[0]);          // x_0, the parent of every block head
+    const float halo = dpp_f<kDppPrev>(y[W - 1]);  // x_{i-1} of this lane's first coordinate lives in the previous lane
+    const float c0 = y0 - mu;
+    float acc = (l.q == 0) ? a * c0 * c0 : 0.0f;  // the x_0 term opens the chain of the first range
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const int i = l.d0 + j;
+      if (i >= 1 && i < D) {
+        const bool head = (tp.mask[i >> 6] >> (i & 63)) & 1ull;
+        const float prev = (j > 0) ? y[j > 0 ? j - 1 : 0] : halo;
+        const float parent = head ? y0 : prev;
+        const float r = y[j] - parent * parent;
+        acc = fmaf(b * r, r, acc);
+      }
+      if ((j & 7) == 7) sched_fence_soft();
+    }
+    return -quad_tree_add(acc);
+  }
+};
+
+template <int W, int MIN_OWN>
+struct QIIDGamma {
+  static constexpr int kKind = PTRWM_TARGET_IID_GAMMA;
+  __device__ __forceinline__ static float logp(const float (&y)[W], const QLane &l, int, const TParams &tp) {
+#pragma clang fp contract(off)
+    const float km1 = (tp.p[0] - 1.0f) * kLn2;
+    const float inv_theta = 1.0f / tp.p[1];
+    float acc = 0.0f;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      if (q_valid<MIN_OWN>(l, j)) {
+        const float v = y[j];
+        bad = bad || (v <= 0.0f);
+        acc += fmaf(km1, hw_log2(v), -(v * inv_theta));
+      }
+      if ((j & 7) == 7) sched_fence_soft();
+    }
+    const float tot = quad_tree_add(acc);
+    return quad_any(bad) ? kNegInf : tot - tp.p[2];
+  }
+};
+
+template <int W, int MIN_OWN>
+struct QIIDBeta {
+  static constexpr int kKind = PTRWM_TARGET_IID_BETA;
+  __device__ __forceinline__ static float logp(const float (&y)[W], const QLane &l, int, const TParams &tp) {
+#pragma clang fp contract(off)
+    const float am1 = (tp.p[0] - 1.0f) * kLn2;
+    const float bm1 = (tp.p[1] - 1.0f) * kLn2;
+    float acc = 0.0f;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      if (q_valid<MIN_OWN>(l, j)) {
+        const float v = y[j];
+        bad = bad || (v <= 0.0f) || (v >= 1.0f);
+        acc += fmaf(am1, hw_log2(v), bm1 * hw_log2(1.0f - v));
+      }
+      if ((j & 7) == 7) sched_fence_soft();
+    }
+    const float tot = quad_tree_add(acc);
+    return quad_any(bad) ? kNegInf : tot + tp.p[2];
+  }
+};
+
+template <int W, int MIN_OWN>
+struct QDiagGaussian {
+  static constexpr int kKind = PTRWM_TARGET_DIAG_GAUSSIAN;
+  template <bool SCALED_FORM>
+  __device__ __forceinline__ static float quad(const float (&y)[W], const QLane &l, const TParams &tp) {
+#pragma clang fp contract(off)
+    const float *v0 = tp.vec0 + l.d0;
+    [[maybe_unused]] const float *v1 = SCALED_FORM ? nullptr : tp.vec1 + l.d0;
+    float qd = 0.0f;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      if (q_valid<MIN_OWN>(l, j)) {
+        if constexpr (SCALED_FORM) {
+          const float sx = v0[j] * y[j];
+          qd = fmaf(sx, sx, qd);
+        } else {
+          const float c = y[j] - v0[j];
+          qd = fmaf(c * v1[j], c, qd);
+        }
+      }
+      if ((j & 7) == 7) sched_fence_soft();
+    }
+    return quad_tree_add(qd);
+  }
+  __device__ __forceinline__ static float logp(const float (&y)[W], const QLane &l, int, const TParams &tp) {
+#pragma clang fp contract(off)
+    const float qd = tp.ip[0] != 0 ? quad<true>(y, l, tp) : quad<false>(y, l, tp);
+    return fmaf(-0.5f, qd, tp.p[0]);
+  }
+};
+
+template <int W, int MIN_OWN>
+struct QHypercube {
+  static constexpr int kKind = PTRWM_TARGET_HYPERCUBE;
+  __device__ __forceinline__ static float logp(const float (&y)[W], const QLane &l, int, const TParams &tp) {
+#pragma clang fp contract(off)
+    const float lo = tp.p[0], hi = tp.p[1];
+    bool outside = false;
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+      if (q_valid<MIN_OWN>(l, j)) outside = outside || !((y[j] >= lo) && (y[j] <= hi));
+    return quad_any(outside) ? kNegInf : tp.p[2];
+  }
+};
+
+template <int W, int MIN_OWN>
+struct QNealFunnel {
+  static constexpr int kKind = PTRWM_TARGET_NEAL_FUNNEL;
+  __device__ __forceinline__ static float logp(const float (&y)[W], const QLane &l, int D, const TParams &tp) {
+#pragma clang fp contract(off)
+    const float mu_v = tp.p[0], s2 = tp.p[1], mu_z = tp.p[2];
+    const float log_2pi = 1.8378770664093453f;
+    const float v = quad_bcast<0>(y[0]);
+    const float dv = v - mu_v;
+    const float prior = -0.5f * log_2pi - 0.5f * (hw_log2(s2) * kLn2) - 0.5f * (dv * dv) / s2;
+    float ssl = 0.0f;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      if (l.d0 + j >= 1 && q_valid<MIN_OWN>(l, j)) {
+        const float c = y[j] - mu_z;
+        ssl = fmaf(c, c, ssl);
+      }
+      if ((j & 7) == 7) sched_fence_soft();
+    }
+    const float ss = quad_tree_add(ssl);
+    const float dm1 = (float)(D - 1);
+    const float lik = -0.5f * dm1 * log_2pi - 0.5f * dm1 * v - 0.5f * hw_exp(-v) * ss;
+    return D > 1 ? prior + lik : prior;
+  }
+};
+
+// ---- the kernel ------------------------------------------------------------------------------------------------------
+// dynamic LDS bytes of a workgroup: per replica slot a row of up to 4 W floats plus the six words of kernel.h's swap
+// machinery (log-density, swap uniform, outcome; three spare) -> (W + 2) floats per thread
+constexpr unsigned quad_kernel_lds_bytes(int threads, int w) { return (unsigned)(threads * (w + 2)) * 4u; }
+// widest workgroup: one ladder of up to kQuadMaxTemps temperatures (wider ladders run the one-thread-per-replica kernel)
+constexpr int kQuadMaxThreads = 512;
+constexpr int kQuadMaxTemps = kQuadMaxThreads / kQuad;
+
+// W      lane register width = canonical range width (8 / 16 / 28)
+// DEXACT dim compiled in (0: run-time dim, any value the width class covers)
+template <class Target, class Proposal, int W, int DEXACT, bool FULL>
+__global__ void __launch_bounds__(kQuadMaxThreads) ptrwm_quad_step_kernel(const KArgs a) {
+  const int T = a.n_temps;
+  const int D = DEXACT ? DEXACT : a.dim;
+  const int cpw = a.chains_per_wave;  // ladders per exchange group (narrow: 16 / T per wave; wide: 1 per workgroup)
+  const bool wide = 4 * T > 64;       // grid-uniform
+  const int tid = wide ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+  const int gthreads = wide ? ((4 * T + 63) & ~63) : 64;
+  const int nslots = gthreads >> 2;
+  const long long chain0 =
+      (wide ? (long long)blockIdx.x : (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * cpw;
+  if (chain0 >= a.n_chains) return;  // narrow only (wave-uniform; narrow waves never meet at a workgroup barrier)
+  const int slot_raw = tid >> 2;
+  QLane l;
+  l.q = tid & 3;
+  l.d0 = l.q * W;
+  {
+    const int left = D - l.d0;
+    l.n_own = left < 0 ? 0 : (left > W ? W : left);
+  }
+  const int cw_raw = slot_raw / T;
+  const int t_raw = slot_raw - cw_raw * T;
+  const bool live = (cw_raw < cpw) && (chain0 + cw_raw < a.n_chains);
+  // idle quads shadow replica (chain0, 0): they compute but never store and are never an exchange source
+  const int slot = live ? slot_raw : 0;
+  const int cw = live ? cw_raw : 0;
+  const int t = live ? t_raw : 0;
+  const long long chain = chain0 + cw;
+  const long long rep = chain0 * T + slot;
+
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  float *const rows = s_dyn + (wide ? 0 : (int)(threadIdx.x >> 6) * (64 * (W + 2)));
+  float *const s_l = rows + nslots * (4 * W);
+  float *const s_u = s_l + nslots;
+  int *const s_landed = reinterpret_cast<int *>(s_u + nslots);
+  auto sync_group = [&]() {
+    if (wide) {
+      __syncthreads();
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+  constexpr int MIN_OWN = DEXACT ? (DEXACT - 3 * W > 0 ? (DEXACT - 3 * W > W ? W : DEXACT - 3 * W) : 0) : 0;
+
+  // ---- state load: the group's live replicas are one contiguous run of floats: coalesced copy into the slab, then
+  // every lane picks its quarter of its replica's row (row stride = dim)
+  float x[W], y[W];
+  {
+    const long long live_chains = (a.n_chains - chain0 < cpw) ? (a.n_chains - chain0) : cpw;
+    const int stage_total = (int)live_chains * T * D;
+    stage_copy(rows, a.state + chain0 * T * (long long)D, stage_total, tid, gthreads);
+    sync_group();
+    const float *seg = rows + slot * D + l.d0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      x[j] = q_valid<MIN_OWN>(l, j) ? seg[j] : 0.0f;
+      y[j] = 0.0f;
+    }
+  }
+  float lp = a.logp[rep];
+  const float beta_t = a.beta[t];
+  const float tscale = a.temp_scale[t];
+
+  const unsigned long long gchain = (unsigned long long)(a.chain_offset + chain);
+  RngCtx rc;
+  rc.c2 = (uint32_t)gchain;
+  rc.k0 = a.k0;
+  rc.k1 = a.k1;
+  const uint32_t c3_base = (uint32_t)t | ((uint32_t)(gchain >> 32) << 12);
+
+  unsigned n_acc = 0, n_swap_acc = 0;
+  int last_event = -1;
+  double sq = 0.0;
+
+  const bool ext = FULL && a.full.ext_prop != nullptr;
+  const bool trace_on =
+      FULL && live && a.full.trace != nullptr && (chain < a.full.trace_chains) && (t < a.full.trace_temps);
+  int to_swap = a.steps_to_swap;
+  int to_trace = FULL ? a.full.steps_to_trace : 0;
+  int trace_rows = 0;
+  int swap_in_call = 0;
+  const int ev_par0 = (int)(a.first_swap_event & 1);
+  unsigned long long s = (unsigned long long)a.step0;
+
+  for (int i = 0; i < a.n_steps; ++i, ++s) {
+    const bool count_on = i >= a.burn_left;
+    --to_swap;
+    const bool multiple = (to_swap == 0);
+    if (multiple) to_swap = a.swap_every;
+    const bool swap_due = multiple && count_on && (T > 1);
+
+    rc.c0hi = (uint32_t)(s >> 32) << 16;
+    rc.c1 = (uint32_t)s;
+    rc.c3 = c3_base | (kStreamMH << 8);
+
+    long long srep = 0;
+    const float *ext_rep = nullptr;
+    float ext_u = 0.0f;
+    if constexpr (FULL) {
+      srep = ((long long)i * a.n_chains + chain) * T + t;
+      if (ext) {
+        ext_rep = a.full.ext_prop + srep * a.full.n_raw_ext;
+        ext_u = a.full.ext_u[srep];
+      }
+    }
+
+    const float u_acc = Proposal::propose(y, x, l, D, tscale, a.pp, rc, ext_rep, ext_u);
+    const float lp_new = Target::logp(y, l, D, a.tp);
+
+    const bool acc = mh_accept(beta_t, lp_new, lp, u_acc);
+    const float lp_mh = acc ? lp_new : lp;
+    if constexpr (FULL) {
+      if (a.full.accept_flags != nullptr && live && l.q == 0) a.full.accept_flags[srep] = acc ? 1 : 0;
+    }
+
+    float j2l = 0.0f;  // this lane's range of the squared jump
+    float j2;
+    if (!swap_due) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        if (q_valid<MIN_OWN>(l, j)) {
+          const float dl = sub_rn(y[j], x[j]);
+          j2l = fmaf(dl, dl, j2l);
+          x[j] = acc ? y[j] : x[j];
+        }
+      }
+      j2 = quad_tree_add(j2l);
+      if (!acc) j2 = 0.0f;
+      lp = lp_mh;
+    } else {
+      // ---- temperature swaps on the post-MH log-densities: kernel.h's swap_decide over replica slots ----------
+      const int base = live ? slot - t : 0;
+      int src = slot;
+      float my_l = lp_mh;
+      bool pair_acc = false;
+      float us;
+      if (ext) {
+        us = (t < T - 1) ? a.full.ext_swap_u[((long long)swap_in_call * a.n_chains + chain) * (T - 1) + t] : 2.0f;
+      } else {
+        const u32x4 r = philox4x32_10(rc.c0hi, rc.c1, rc.c2, c3_base | (kStreamSwap << 8), rc.k0, rc.k1);
+        us = u01(r.x);
+      }
+      // (the previous event's reads of s_l / the outcome slots are separated from these writes by its two row-exchange
+      // synchronisations)
+      s_l[slot_raw] = my_l;  // the four lanes of a quad write the same value
+      s_u[slot_raw] = us;
+      sync_group();
+      swap_decide(T, t, base, slot, a.swap_mode, a.swap_order, (ev_par0 + swap_in_call) & 1, a.beta, beta_t, us, s_l, s_u,
+                  s_landed, my_l, src, pair_acc);
+      if (pair_acc) {
+        n_swap_acc += 1;
+        last_event = swap_in_call;
+      }
+      {
+        float *my_seg = rows + slot_raw * D + l.d0;
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+          if (q_valid<MIN_OWN>(l, j)) my_seg[j] = acc ? y[j] : x[j];
+        sync_group();
+        const float *src_seg = rows + src * D + l.d0;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          if (q_valid<MIN_OWN>(l, j)) {
+            const float w = src_seg[j];
+            const float dl = sub_rn(w, x[j]);
+            j2l = fmaf(dl, dl, j2l);
+            x[j] = w;
+          }
+        }
+        j2 = quad_tree_add(j2l);
+      }
+      lp = my_l;
+      ++swap_in_call;
+    }
+
+    if (count_on) {
+      n_acc += acc ? 1u : 0u;
+      sq += (double)j2;
+    }
+    if constexpr (FULL) {
+      bool trace_now = false;
+      if (a.full.trace != nullptr) {
+        --to_trace;
+        trace_now = (to_trace == 0);
+        if (trace_now) to_trace = a.full.trace_every;
+      }
+      if (trace_now && trace_on) {
+        const long long row = ((a.full.trace_row0 + trace_rows) * a.full.trace_chains + chain) * a.full.trace_temps + t;
+        float *__restrict__ tr = a.full.trace + row * D + l.d0;
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+          if (q_valid<MIN_OWN>(l, j)) tr[j] = x[j];
+        if (a.full.trace_logp != nullptr && l.q == 0) a.full.trace_logp[row] = lp;
+      }
+      trace_rows += trace_now ? 1 : 0;
+    }
+  }
+
+  // ---- state store: quarters -> slab rows -> coalesced HBM writes ---------------------------------------------
+  {
+    const long long live_chains = (a.n_chains - chain0 < cpw) ? (a.n_chains - chain0) : cpw;
+    const int stage_total = (int)live_chains * T * D;
+    sync_group();  // the last swap's row reads are done before the rows are overwritten
+    if (live) {
+      float *seg = rows + slot * D + l.d0;
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+        if (q_valid<MIN_OWN>(l, j)) seg[j] = x[j];
+    }
+    sync_group();
+    stage_copy(a.state + chain0 * T * (long long)D, rows, stage_total, tid, gthreads);
+  }
+  if (live && l.q == 0) {
+    a.logp[rep] = lp;
+    if (a.n_accept != nullptr) a.n_accept[rep] += (long long)n_acc;
+    if (a.sq_jump != nullptr) a.sq_jump[rep] += sq;
+    if (a.swap_accept != nullptr) a.swap_accept[rep] += (long long)n_swap_acc;
+    if (a.last_swap_ordinal != nullptr && last_event >= 0) {
+      const long long ev = a.first_swap_event + last_event;
+      const long long ord = (a.swap_order == PTRWM_ORDER_SEQUENTIAL) ? ev * (T - 1) + t + 1 : ev + 1;
+      if (ord > a.last_swap_ordinal[rep]) a.last_swap_ordinal[rep] = ord;
+    }
+  }
+}
+
+}  // namespace ptrwm

@@ -4,6 +4,7 @@
 // per-thread register arrays, the smallest entry of kDP that is >= dim.
 #pragma once
 #include "kernel.h"
+#include "quad.h"
 
 namespace ptrwm {
 
@@ -102,6 +103,83 @@ hipError_t launch_logp(const float *x, float *out, long long n, int D, const TPa
   return hipGetLastError();
 }
 
+// ---- lane-split ("quad") variants (quad.h): X(lane width W, dim compiled in or 0 for a run-time dim) ---------------
+// W is the canonical range width of the dim class (8 / 16 / 28 for dim <= 32 / 64 / 112); the BASELINE dims get a
+// kernel with dim compiled in, every other dim runs the generic kernel of its class.
+#define PTRWM_QUAD_WIDTHS(X) X(8, 0) X(8, 30) X(16, 0) X(16, 50) X(28, 0) X(28, 100)
+struct QuadWidthInfo {
+  int w, dexact;
+};
+#define PTRWM_X_QINFO(W, E) {W, E},
+constexpr QuadWidthInfo kQuadWidths[] = {PTRWM_QUAD_WIDTHS(PTRWM_X_QINFO)};
+#undef PTRWM_X_QINFO
+constexpr int kNumQuadWidths = (int)(sizeof(kQuadWidths) / sizeof(kQuadWidths[0]));
+#define PTRWM_X_QOK(W, E) static_assert(W == canon_width(4 * W) && (E == 0 || (E <= 4 * W && canon_width(E) == W)), "quad width table");
+PTRWM_QUAD_WIDTHS(PTRWM_X_QOK)
+#undef PTRWM_X_QOK
+
+// the kernel with this dim compiled in if there is one, else the generic kernel of the dim's class; -1 if none
+inline int quad_index_for_dim(int dim) {
+  if (dim < 1 || dim > PTRWM_MAX_DIM) return -1;
+  int best = -1;
+  for (int i = 0; i < kNumQuadWidths; ++i) {
+    if (kQuadWidths[i].dexact == dim) return i;
+    if (kQuadWidths[i].dexact == 0 && kQuadWidths[i].w == canon_width(dim)) best = i;
+  }
+  return best;
+}
+
+struct QuadVariants {
+  RunLaunchFn run[PTRWM_PROPOSAL_COUNT][kNumQuadWidths];
+};
+
+// MIN_OWN of quad.h: the number of dimensions the LAST lane owns when dim is compiled in (every lane owns at least that)
+constexpr int quad_min_own(int w, int dexact) {
+  return dexact == 0 ? 0 : (dexact - 3 * w <= 0 ? 0 : (dexact - 3 * w > w ? w : dexact - 3 * w));
+}
+
+template <class Target, class Proposal, int W, int DEXACT>
+hipError_t launch_run_quad(const KArgs &a, unsigned grid, bool full, hipStream_t stream) {
+  // narrow ladders (4 T <= 64): four independent one-wave groups per workgroup; wide ones: one ladder per workgroup
+  const unsigned block = 4 * a.n_temps > 64 ? (unsigned)((4 * a.n_temps + 63) & ~63) : (unsigned)kBlockThreads;
+  const unsigned lds = quad_kernel_lds_bytes((int)block, W);
+  auto kfull = ptrwm_quad_step_kernel<Target, Proposal, W, DEXACT, true>;
+  auto kprod = ptrwm_quad_step_kernel<Target, Proposal, W, DEXACT, false>;
+  if (lds > 48u * 1024u) {  // raise the dynamic-LDS allowance once per kernel and device (see launch_run)
+    constexpr int kMaxDevices = 64;
+    static unsigned long long raised_mask = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    const bool known = dev >= 0 && dev < kMaxDevices;
+    if (!known || !((__atomic_load_n(&raised_mask, __ATOMIC_ACQUIRE) >> dev) & 1ull)) {
+      const int cap = (int)quad_kernel_lds_bytes(kQuadMaxThreads, W);
+      hipError_t e = hipFuncSetAttribute((const void *)kfull, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)kprod, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+      if (e != hipSuccess) return e;
+      if (known) __atomic_fetch_or(&raised_mask, 1ull << dev, __ATOMIC_RELEASE);
+    }
+  }
+  if (full)
+    hipLaunchKernelGGL(kfull, dim3(grid), dim3(block), lds, stream, a);
+  else
+    hipLaunchKernelGGL(kprod, dim3(grid), dim3(block), lds, stream, a);
+  return hipGetLastError();
+}
+
+#define PTRWM_X_QRUN_N(W, E) launch_run_quad<QTGT<W, quad_min_own(W, E)>, QNormal<W, quad_min_own(W, E)>, W, E>,
+#define PTRWM_X_QRUN_L(W, E) launch_run_quad<QTGT<W, quad_min_own(W, E)>, QLaplace<W, quad_min_own(W, E)>, W, E>,
+#define PTRWM_X_QRUN_U(W, E) launch_run_quad<QTGT<W, quad_min_own(W, E)>, QUniformRadius<W, quad_min_own(W, E)>, W, E>,
+// One translation unit per target (csrc/quad_<target>.hip) defines its table with this macro.
+#define PTRWM_DEFINE_QUAD_VARIANTS(SYMBOL, QTARGET)                        \
+  template <int W, int M>                                                  \
+  using QTGT = QTARGET<W, M>;                                              \
+  const QuadVariants &SYMBOL##_quad() {                                    \
+    static const QuadVariants v = {{{PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN_N)},   \
+                                    {PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN_L)},   \
+                                    {PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN_U)}}}; \
+    return v;                                                              \
+  }
+
 // One translation unit per target (compiled in parallel) defines its table with this macro.
 // The table lives inside a host function so the device pass does not try to emit it.
 #define PTRWM_X_RUN_N(W, E) launch_run<TGT<W>, NormalProposal<W>, W, E>,
@@ -130,7 +208,8 @@ hipError_t launch_logp(const float *x, float *out, long long n, int D, const TPa
 
 #define PTRWM_DECLARE_TARGET_VARIANTS(SYMBOL) \
   const TargetVariants &SYMBOL##_narrow();    \
-  const TargetVariants &SYMBOL##_wide();
+  const TargetVariants &SYMBOL##_wide();      \
+  const QuadVariants &SYMBOL##_quad();
 PTRWM_DECLARE_TARGET_VARIANTS(rough_carpet_variants)
 PTRWM_DECLARE_TARGET_VARIANTS(rough_carpet2_variants)  // two-term specialisation, see targets.h
 PTRWM_DECLARE_TARGET_VARIANTS(three_mixture_variants)

@@ -44,6 +44,9 @@ SWAP_REFERENCE_COPY = 1
 ORDER_SEQUENTIAL = 0
 ORDER_EVEN_ODD = 1
 
+# form of the fused step kernel (ptrwm_set_kernel_form): a speed choice only, results are bit-identical
+FORM_AUTO, FORM_THREAD, FORM_QUAD = 0, 1, 2
+
 SWAP_MODES = {"exchange": SWAP_EXCHANGE, "reference_copy": SWAP_REFERENCE_COPY}
 SWAP_ORDERS = {"sequential": ORDER_SEQUENTIAL, "even_odd": ORDER_EVEN_ODD}
 
@@ -116,6 +119,8 @@ SYMBOLS = {
     "ptrwm_strerror": (C.c_char_p, [C.c_int32]),
     "ptrwm_ext_raw_per_step": (C.c_int32, [C.c_int32, C.c_int32]),
     "ptrwm_has_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    "ptrwm_set_kernel_form": (C.c_int32, [C.c_int32]),
+    "ptrwm_has_quad_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "ptrwm_run": (C.c_int32, [C.POINTER(TargetDesc), C.POINTER(ProposalDesc), C.POINTER(RunArgs), C.c_void_p]),
     "ptrwm_swap_sweep": (C.c_int32, [C.POINTER(RunArgs), C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "ptrwm_split_propose": (
@@ -155,6 +160,9 @@ def load_library(path: Optional[str] = None):
         fn.argtypes = argtypes
     if lib.ptrwm_abi_version() != ABI_VERSION:
         raise RuntimeError(f"ABI mismatch: library {lib.ptrwm_abi_version()} vs binding {ABI_VERSION}")
+    form = os.environ.get("PTRWM_KERNEL_FORM")  # tuning aid: auto | thread | quad (results are identical)
+    if form:
+        lib.ptrwm_set_kernel_form({"auto": FORM_AUTO, "thread": FORM_THREAD, "quad": FORM_QUAD}[form.lower()])
     if path is None:
         _lib = lib
     return lib
@@ -261,6 +269,34 @@ def ext_raw_per_step(proposal_kind: int, dim: int) -> int:
 
 def has_variant(target_kind: int, proposal_kind: int, dim: int) -> bool:
     return bool(load_library().ptrwm_has_variant(target_kind, proposal_kind, dim))
+
+
+def has_quad_variant(target_kind: int, proposal_kind: int, dim: int, n_temps: int) -> bool:
+    return bool(load_library().ptrwm_has_quad_variant(target_kind, proposal_kind, dim, n_temps))
+
+
+def set_kernel_form(form: int) -> int:
+    """Pin the form of the fused step kernel (FORM_AUTO / FORM_THREAD / FORM_QUAD); returns the previous setting.
+    The forms are bit-identical on the same Philox stream: this changes speed only (tests and tuning)."""
+    prev = load_library().ptrwm_set_kernel_form(form)
+    if prev < 0:
+        raise PTRWMError(prev, "ptrwm_set_kernel_form")
+    return prev
+
+
+class kernel_form:
+    """Context manager around set_kernel_form."""
+
+    def __init__(self, form: int):
+        self.form = form
+
+    def __enter__(self):
+        self.prev = set_kernel_form(self.form)
+        return self
+
+    def __exit__(self, *exc):
+        set_kernel_form(self.prev)
+        return False
 
 
 def logdensity(target: Target, x: torch.Tensor) -> torch.Tensor:

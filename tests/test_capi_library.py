@@ -86,6 +86,16 @@ def test_validation_needs_no_gpu(engine):
             assert all(engine.has_variant(t, p, d) for d in (1, 2, 3, 5, 24, 30, 31, 41, 50, 57, 64, 65, 81, 100, 104))
             assert not engine.has_variant(t, p, 105) and not engine.has_variant(t, p, 0)
     assert not engine.has_variant(10, 0, 30) and not engine.has_variant(0, 3, 30)
+    # lane-split variants: every dim, ladders of up to 128 temperatures
+    for t in range(10):
+        for p in range(3):
+            assert all(engine.has_quad_variant(t, p, d, n) for d in (1, 30, 32, 33, 50, 64, 65, 100, 104) for n in (1, 16, 17, 128))
+            assert not engine.has_quad_variant(t, p, 30, 129) and not engine.has_quad_variant(t, p, 105, 4)
+    # the kernel-form switch: returns the previous setting, rejects unknown values
+    assert engine.set_kernel_form(engine.FORM_QUAD) == engine.FORM_AUTO
+    assert engine.set_kernel_form(engine.FORM_AUTO) == engine.FORM_QUAD
+    with pytest.raises(engine.PTRWMError):
+        engine.set_kernel_form(3)
 
     td, pd, ra = engine.TargetDesc(), engine.ProposalDesc(), engine.RunArgs()
     assert lib.ptrwm_run(None, None, None, None) == -1

@@ -345,6 +345,69 @@ def test_external_randoms_vs_oracle(device, tkey, pkind, T, Cn, pkw, mode, order
     logp_close(got["trace_logp"], own, extra_abs=3e-4)
 
 
+@pytest.mark.parametrize("tkey,pkind,T,Cn,pkw", SWEEP, ids=[f"{s[0]}-{s[1]}-T{s[2]}" for s in SWEEP])
+@pytest.mark.parametrize("mode,order", [("exchange", "sequential"), ("reference_copy", "even_odd")])
+def test_lane_split_kernel_vs_oracle(device, tkey, pkind, T, Cn, pkw, mode, order):
+    """The lane-split (quad) form of the fused kernel (csrc/quad.h: four lanes per replica, chosen by the C ABI for
+    under-filled launches and large dims) directly against the oracle over the full horizon, every family, with the
+    form pinned - so its correctness does not rest on its bit-identity with the one-thread-per-replica kernel alone."""
+    spec = H.target_spec(tkey)
+    if not E.has_quad_variant(spec.kind, H.PROPOSAL_KIND[pkind], spec.dim, T):
+        pytest.skip("no lane-split variant for this shape")
+    rng = np.random.default_rng(zlib.crc32(f"quad-{tkey}-{pkind}-{T}".encode()))
+    beta = (0.05 ** (np.arange(T) / max(1, T - 1))).astype(np.float32)
+    prop = H.proposal_spec(pkind, spec.dim, beta, **pkw)
+    N, burn, se = 60, 7, 4
+    raw = O.ext_raw_per_step(prop.kind, spec.dim)
+    ext = _ext_arrays(rng, pkind, N, Cn, T, raw)
+    us = rng.random((N // se - burn // se, Cn, max(T - 1, 1))).astype(np.float32)[:, :, :T - 1]
+    st, lp = start_state(spec, Cn, T, rng)
+    with E.kernel_form(E.FORM_QUAD):
+        H.check_parity(gpu_runner(spec, prop, device), H.oracle_runner(spec, prop), spec, prop, exact_states=pkind == "Normal",
+                       state=st, logp=lp, beta=beta, n_steps=N, burn_in=burn, swap_every=se, ext_prop=ext,
+                       ext_u=rng.random((N, Cn, T)).astype(np.float32), ext_swap_u=us if T > 1 else None,
+                       swap_mode=E.SWAP_MODES[mode], swap_order=E.SWAP_ORDERS[order])
+
+
+def test_form_selection_never_changes_a_result(device):
+    """The C ABI picks the kernel form from the batch size (csrc/capi.hip, AUTO): a whole batch large enough for the
+    one-thread-per-replica kernel and its two halves small enough for the lane-split kernel must give the SAME bits
+    (the multi-GPU sharding rule would otherwise depend on the shard size), and so must the pinned forms."""
+    spec = H.target_spec("rc15_d30")
+    T, Cn, N = 1, 160000, 40  # 2 500 waves (2.4 per SIMD) -> thread form; halves: 1 250 waves -> lane-split form
+    beta = np.ones(1, np.float32)
+    prop = H.proposal_spec("Normal", 30, [1.0], base_variance_scalar=2.38**2 / 30, single=True)
+    st, lp = start_state(spec, Cn, T, np.random.default_rng(3))
+    kw = dict(beta=beta, step0=0, n_steps=N, burn_in=5, swap_every=1, seed=99)
+    whole = gpu_run(spec, prop, device, state=st, logp=lp, chain_offset=1000, **kw)
+    lo = gpu_run(spec, prop, device, state=st[:Cn // 2], logp=lp[:Cn // 2], chain_offset=1000, **kw)
+    hi = gpu_run(spec, prop, device, state=st[Cn // 2:], logp=lp[Cn // 2:], chain_offset=1000 + Cn // 2, **kw)
+    for k in ("state", "logp", "n_accept", "sq_jump"):
+        assert np.array_equal(whole[k], np.concatenate([lo[k], hi[k]])), k
+    for form in (E.FORM_THREAD, E.FORM_QUAD):
+        with E.kernel_form(form):
+            pinned = gpu_run(spec, prop, device, state=st[:4096], logp=lp[:4096], chain_offset=1000, **kw)
+        for k in ("state", "logp", "n_accept", "sq_jump"):
+            assert np.array_equal(pinned[k], whole[k][:4096]), (k, form)
+    assert E.set_kernel_form(E.FORM_AUTO) == E.FORM_AUTO  # the context managers restored it
+    with pytest.raises(E.PTRWMError):
+        E.set_kernel_form(7)
+
+
+def test_lane_split_kernel_is_bit_identical_to_the_thread_kernel(device):
+    """tools/check_quad.py: every target kernel x proposal x lane width (generic and dim-compiled-in) on a fixed grid plus
+    60 random configurations; production and fixture variants, Philox and external randoms, narrow and wide ladders:
+    states, log-densities, all statistics (fp64 bits), traces and accept flags identical between the two forms."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_quad.py"), "60", "5"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
+    assert "kernels bit-identical" in r.stdout and "MISMATCH" not in r.stdout
+
+
 @pytest.mark.parametrize("tkey,pkind,T,Cn,pkw", SWEEP[:6], ids=[f"{s[0]}-{s[1]}-T{s[2]}" for s in SWEEP[:6]])
 def test_philox_mode_vs_oracle(device, tkey, pkind, T, Cn, pkw):
     """In-kernel Philox against the oracle's restatement of the same counter layout (same seed, same chain ids):
