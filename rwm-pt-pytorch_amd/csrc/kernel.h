@@ -209,6 +209,9 @@ __device__ __forceinline__ int fresh_dim(int d0) {
 
 // Register budget: the replica's x[DP] and y[DP] plus ~30 temporaries must stay in VGPRs.  Without a
 // bound hipcc hoists every Philox block of a step ahead of its consumers and lands far above that.
+#ifndef PTRWM_J2_FENCE_MASK  // fence cadence of the update / squared-jump loop (A/B-timed, tools/ab_bench.sh)
+#define PTRWM_J2_FENCE_MASK 7
+#endif
 #ifndef PTRWM_WAVES_SMALL  // tuning knobs (profiles/r01_bench_variants.txt: 4 beats 3, 5 and 6 at dim 30)
 #define PTRWM_WAVES_SMALL 4
 #endif
@@ -353,6 +356,19 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     constexpr int W = canon_width(DP);
     float j2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // squared jump in the canonical four-range order (philox.h)
     if (!swap_due) {
+#ifdef PTRWM_J2_SEPARATE
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        if (d < D) {
+          const float dl = sub_rn(y[d], x[d]);
+          j2p[d / W] = fmaf(dl, dl, j2p[d / W]);
+        }
+        if ((d & PTRWM_J2_FENCE_MASK) == PTRWM_J2_FENCE_MASK) sched_fence_soft();
+      }
+#pragma unroll
+      for (int d = 0; d < DP; ++d)
+        if (d < D) x[d] = acc ? y[d] : x[d];
+#else
 #pragma unroll
       for (int d = 0; d < DP; ++d) {
         if (d < D) {
@@ -360,8 +376,9 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
           j2p[d / W] = fmaf(dl, dl, j2p[d / W]);
           x[d] = acc ? y[d] : x[d];
         }
-        if ((d & 7) == 7) sched_fence_soft();
+        if ((d & PTRWM_J2_FENCE_MASK) == PTRWM_J2_FENCE_MASK) sched_fence_soft();
       }
+#endif
       j2 = tree4_add(j2p);
       if (!acc) j2 = 0.0f;
       lp = lp_mh;

@@ -51,6 +51,14 @@ __device__ __forceinline__ void rc_dim_term(float d0, float d1, float d2, float 
   }
 }
 
+// scheduling knob: a fence after every (MASK + 1) dimensions of the rough-carpet loop.  The max-ILP schedule of the
+// ~1 500-instruction step loop moves by several per cent with the placement of the fences; candidates are A/B-timed on
+// one box (tools/ab_bench.sh).  With the canonical four-range sums a fence every 4 dimensions cost 3.5 % on BASELINE
+// configs[2] (113.4 against 109.5 ms per 2 000-step launch); 8, 16 and no fences measured the same (109.2-109.5).
+#ifndef PTRWM_RC_FENCE_MASK
+#define PTRWM_RC_FENCE_MASK 7
+#endif
+
 template <int DP, bool TWO_TERM>
 struct RoughCarpetT {
   static constexpr int kKind = PTRWM_TARGET_ROUGH_CARPET;
@@ -83,10 +91,15 @@ struct RoughCarpetT {
         }
         float mx, s;
         rc_dim_term<STRICT, TWO>(d0, d1, d2, nh, w0, w1, w2, mx, s);
+#ifdef PTRWM_RC_PROD_FIRST
+        pr[d / W] = mul_rn(pr[d / W], s);
+        sm[d / W] = add_rn(sm[d / W], mx);
+#else
         sm[d / W] = add_rn(sm[d / W], mx);
         pr[d / W] = mul_rn(pr[d / W], s);
+#endif
       }
-      if ((d & 3) == 3) sched_fence_soft();
+      if ((d & PTRWM_RC_FENCE_MASK) == PTRWM_RC_FENCE_MASK) sched_fence_soft();
     }
     const float sum_mx = tree4_add(sm);
     // each factor is in [1, 3] and a range holds at most 28 of them: the product of two ranges (<= 3^56) cannot

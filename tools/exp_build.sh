@@ -10,7 +10,8 @@ cat > $OBJ/stubs.hip <<'EOS'
 #include "../csrc/variants.h"
 namespace ptrwm {
 #define STUB(fn) const TargetVariants &fn##_narrow() { static const TargetVariants v = {}; return v; } \
-                 const TargetVariants &fn##_wide() { static const TargetVariants v = {}; return v; }
+                 const TargetVariants &fn##_wide() { static const TargetVariants v = {}; return v; } \
+                 const QuadVariants &fn##_quad() { static const QuadVariants v = {}; return v; }
 STUB(three_mixture_variants) STUB(full_rosenbrock_variants) STUB(even_rosenbrock_variants)
 STUB(hybrid_rosenbrock_variants) STUB(iid_gamma_variants) STUB(iid_beta_variants) STUB(diag_gaussian_variants)
 STUB(hypercube_variants) STUB(neal_funnel_variants)
@@ -24,8 +25,10 @@ BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function"
 for v in rough_carpet rough_carpet2; do
   /opt/rocm/bin/hipcc $BASE $* -c variants_$v.hip -o $OBJ/variants_$v.o &
   /opt/rocm/bin/hipcc $BASE $PTRWM_EXP_WIDE_FLAGS -DPTRWM_PART_WIDE -c variants_$v.hip -o $OBJ/variants_$v.wide.o &
+  /opt/rocm/bin/hipcc $BASE -fno-slp-vectorize $PTRWM_EXP_QUAD_FLAGS -c quad_$v.hip -o $OBJ/quad_$v.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libptrwm_hip.so $OBJ/capi.o $OBJ/stubs.o \
-  $OBJ/variants_rough_carpet.o $OBJ/variants_rough_carpet.wide.o $OBJ/variants_rough_carpet2.o $OBJ/variants_rough_carpet2.wide.o
+  $OBJ/variants_rough_carpet.o $OBJ/variants_rough_carpet.wide.o $OBJ/variants_rough_carpet2.o $OBJ/variants_rough_carpet2.wide.o \
+  $OBJ/quad_rough_carpet.o $OBJ/quad_rough_carpet2.o
 ls -la $OUT/libptrwm_hip.so
