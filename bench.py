@@ -267,9 +267,18 @@ def main():
             "configs[2] sustained: median of 3 repeats": {
                 "value": reps[1], "min": reps[0], "max": reps[2], "launches_per_repeat": n_rep,
                 "seconds_per_repeat": n_rep * per_launch_s, "mh_steps_per_launch": args.inner},
-            "configs[1]: RWM HIP, RoughCarpet dim 30, Normal proposal, 65536 chains x 1 temperature": quick(
+            "configs[1]: RWM HIP, RoughCarpet dim 30, Normal proposal, 65536 chains x 1 temperature (lane-split form)": quick(
                 lambda: RandomWalkMH_GPU_Optimized(dim, 2.38**2 / dim, target, burn_in=0, device=dev, num_chains=C,
                                                    seed=42), args.inner),
+            "one ladder (the reference's own use: 1 replica x 8 geometric temps), lane-split form": quick(
+                lambda: ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target, geom_temp_spacing=True,
+                                                           swap_every=args.swap_every, burn_in=0, device=dev,
+                                                           num_replicas=1, seed=42, trace="none"), 20000, n=3),
+            "configs[2] at dim 100 (lane-split form: the thread form holds one wave per SIMD there)": quick(
+                lambda: ParallelTemperingRWM_GPU_Optimized(
+                    100, 2.38**2 / 100, RoughCarpetDistributionTorch(100, device=dev, mode_centers=[-15.0, 0.0, 15.0]),
+                    beta_ladder=geometric_beta_ladder(T), swap_every=args.swap_every, burn_in=0, device=dev,
+                    num_replicas=C, seed=42, trace="none"), max(50, args.inner // 10), n=3),
             "configs[2] with swap_order=even_odd": quick(
                 lambda: ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target,
                                                            beta_ladder=geometric_beta_ladder(T),
@@ -364,7 +373,8 @@ def main():
             roof = {"bound": "valu_issue", "achieved": None, "peak": valu_peak / 1e9, "unit": "Gwave-instr/s", "frac": None,
                     "traffic": traffic, "note_counters": f"no PMC record {key!r} in profiles/traffic.json"}
         roof.update({
-            "kernel": f"ptrwm_step_kernel<{type(target).__name__}, {alg.proposal_dist.get_name()}, dim {dim}, production>",
+            "kernel": rec.get("kernel") or f"fused step kernel <{type(target).__name__}, {alg.proposal_dist.get_name()}, dim {dim}, "
+                                           "production>, form chosen by the C ABI",
             "kernel_ms": kernel_ms, "lib_sha256": lib_sha,
             "hbm_counter_traffic": None if traffic is None else {
                 "bytes_per_launch": traffic, "GBps": traffic / (kernel_ms * 1e-3) / 1e9,

@@ -24,6 +24,15 @@ namespace ptrwm {
 
 constexpr int kQuad = 4;
 
+// A lane runs two (dim 30) to seven Philox blocks per step: few enough to let the scheduler interleave them (at four
+// waves per SIMD the dependent rounds of ONE block do not hide their own latency); PTRWM_QUAD_FENCE_RNG restores the
+// per-block fences of the one-thread-per-replica kernel (needed there to bound the registers of eight-plus blocks).
+__device__ __forceinline__ void quad_rng_fence() {
+#ifdef PTRWM_QUAD_FENCE_RNG
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // ---- DPP quad permutes (lane i of a quad reads lane SEL_i; full rate, no LDS) --------------------------------------
 constexpr int quad_ctrl(int s0, int s1, int s2, int s3) { return s0 | (s1 << 2) | (s2 << 4) | (s3 << 6); }
 constexpr int kDppSwapPair = quad_ctrl(1, 0, 3, 2);   // partner inside the pair
@@ -106,7 +115,7 @@ struct QNormal {
           }
           if ((int)(4 * cb) + 2 * h == w_a) u_loc = u01(ra);
         }
-        sched_fence();
+        quad_rng_fence();
       }
     }
     if (c_a >= W) {  // dim = 4 W or 4 W - 1: the accept word opens block W, which no lane owns: all compute it
@@ -144,7 +153,7 @@ struct QLaplace {
           if (q_valid<MIN_OWN>(l, j)) y[j] = add_rn(x[j], LaplaceProposal<W>::transform(u01(pick(r, k)), mul_rn(dsc[j], tscale)));
           if ((int)(4 * cb) + k == D) u_loc = u01(pick(r, k));
         }
-        sched_fence();
+        quad_rng_fence();
       }
     }
     if (c_a >= W) {
@@ -192,7 +201,7 @@ struct QUniformRadius {
               ua_loc = u01(rb);
             }
           }
-          sched_fence();
+          quad_rng_fence();
         }
       }
       if (c_a >= W) {

@@ -770,7 +770,44 @@ def test_long_run_statistics_match_the_reference_anchors(device):
     frac = (pt._run.swap_accept.sum(1).double() / attempts).cpu().numpy()
     cold = (pt._run.sq_jump[:, 0] / n).cpu().numpy()
     check("pt swap acceptance", frac.mean(), frac.std(ddof=1) / np.sqrt(lad), ref["pt"]["swap_accept_fraction"])
+    # cold-chain ESJD: the reference's own Monte-Carlo error (42 runs of 4e5 steps: +-0.4 % at one sigma) is what limits
+    # this comparison, not the 1e-3 bound - the 4 sigma term dominates the tolerance (DESIGN.md section 4 says so)
     check("pt cold esjd", cold.mean(), cold.std(ddof=1) / np.sqrt(lad), ref["pt"]["cold_esjd"])
+
+
+@pytest.mark.parametrize("family", ["rwm_tm_uniform", "rwm_even_laplace"])
+def test_long_run_statistics_of_the_other_baseline_families(device, family):
+    """The families of BASELINE configs[3] / [4] against the reference's RWM class with `proposal_distribution=`
+    (rwm_gpu_optimized.py:402-488; tests/golden/generate_anchors.py `extend`: 14 runs of 1e6 steps each): ThreeMixture
+    dim 50 with the UniformRadius proposal and EvenRosenbrock dim 30 with the Laplace proposal.  Acceptance rate and
+    ESJD within 1e-3 relative plus 4 combined standard errors.  (EvenRosenbrock from its 1e-8 start is still in its
+    transient after 1e6 steps - the reference's own runs scatter by 19 % - so that anchor is loose by nature.)"""
+    import json
+    import os
+
+    with open(os.path.join(H.GOLDEN, "reference_anchors.json")) as f:
+        ref = json.load(f)
+    if family not in ref:
+        pytest.skip("anchor family not generated")
+    a = ref[family]
+    dim, n, burn, chains = a["dim"], a["steps_per_run"], ref["burn_in"], 4096
+    np.random.seed(5)
+    if family == "rwm_tm_uniform":
+        target = ThreeMixtureDistributionTorch(dim, device=device)
+        prop = UniformRadiusProposal(dim, a["proposal_scale"], 1.0, device, torch.float32)
+    else:
+        target = EvenRosenbrockTorch(dim, device=device)
+        prop = LaplaceProposal(dim, torch.full((dim,), a["proposal_scale"]), 1.0, device, torch.float32)
+    alg = RandomWalkMH_GPU_Optimized(dim=dim, target_dist=target, burn_in=burn, device=device, num_chains=chains, seed=11,
+                                     proposal_distribution=prop)
+    alg._ensure_started()
+    alg._run.advance(burn + n)
+    acc = (alg._run.n_accept[:, 0].double() / n).cpu().numpy()
+    esjd = (alg._run.sq_jump[:, 0] / n).cpu().numpy()
+    for name, got, anchor in (("acceptance", acc, a["acceptance_rate"]), ("esjd", esjd, a["esjd"])):
+        se = got.std(ddof=1) / np.sqrt(chains)
+        tol = 1e-3 * abs(anchor["mean"]) + 4.0 * (anchor["stderr"] ** 2 + se ** 2) ** 0.5
+        assert abs(got.mean() - anchor["mean"]) <= tol, (family, name, got.mean(), anchor, tol)
 
 
 def test_bench_emits_the_contract_line(device):

@@ -19,7 +19,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, out = sys.argv[1], sys.argv[2]
 prof = os.path.join(ROOT, "profiles")
-KERNEL = "ptrwm_step_kernel"
+KERNEL = "step_kernel"  # ptrwm_step_kernel (one thread per replica) or ptrwm_quad_step_kernel (lane-split)
 LIB = os.path.join(ROOT, "rwm-pt-pytorch_amd", "lib", "libptrwm_hip.so")
 lib_sha = hashlib.sha256(open(LIB, "rb").read()).hexdigest()
 # cfg -> (traffic.json key, Metropolis steps per launch, description, warm-up launches in the kernel-trace run)
