@@ -133,13 +133,13 @@ enum {
  * ptrwm_run has two bit-identical implementations of the same loop (same Philox words, same per-dimension arithmetic,
  * every sum over dimensions in one canonical order): one thread per (chain, temperature) replica, and a lane-split
  * form with four lanes per replica for launches that would otherwise under-fill the GPU (fewer than two wavefronts
- * per SIMD) or sit at one wavefront per SIMD (dim > 64).  AUTO picks by batch size and dim; the choice cannot change a
- * result, only the speed.  ptrwm_set_kernel_form pins it process-wide (tests, tuning) and returns the previous
+ * per SIMD); above dim 64 only the lane-split form exists.  AUTO picks by batch size and dim; the choice cannot change
+ * a result, only the speed.  ptrwm_set_kernel_form pins it process-wide (tests, tuning) and returns the previous
  * value, or PTRWM_E_ARG. */
 enum {
   PTRWM_FORM_AUTO = 0,
-  PTRWM_FORM_THREAD = 1, /* always one thread per replica */
-  PTRWM_FORM_QUAD = 2    /* lane-split whenever that variant exists (n_temps <= 128), else one thread per replica */
+  PTRWM_FORM_THREAD = 1, /* one thread per replica wherever that variant exists (dim <= 64) */
+  PTRWM_FORM_QUAD = 2    /* lane-split wherever that variant exists (dim <= 64: n_temps <= 128; dim > 64: all) */
 };
 int32_t ptrwm_set_kernel_form(int32_t form);
 /* 1 if ptrwm_run has a lane-split variant for (target, proposal, dim, n_temps), else 0. */

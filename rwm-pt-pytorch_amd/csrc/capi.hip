@@ -27,8 +27,9 @@ struct VariantPair {
 //                    puts four times as many SIMDs to work (2.5-3.2x for a single ladder)
 //   32 < dim <= 64   the four lanes own 16 dims each, so dims well below 64 waste lanes (dim 50: 28 %): lane-split when
 //                    w < 0.75, or always for dim >= 60 (there the thread kernel is held to two waves per SIMD)
-//   dim > 64         the thread kernel's register arrays allow one wave per SIMD: lane-split for ladders of <= 64
-//                    temperatures (1.04-1.25x at full batches, 1.8x at small ones)
+//   dim > 64         lane-split always: it is the only form there (the one-thread-per-replica kernel needed 340-420
+//                    VGPRs - one wave per SIMD, 8-25 % slower at full batches, 1.8x at small ones - and sat in the
+//                    register regime in which hipcc miscompiled it twice; see variants.h)
 static int g_kernel_form = PTRWM_FORM_AUTO;
 constexpr long long kSimds = 1024;  // 256 CUs x 4
 
@@ -389,9 +390,8 @@ int32_t ptrwm_set_kernel_form(int32_t form) {
 int32_t ptrwm_has_quad_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim, int32_t n_temps) {
   if (target_kind < 0 || target_kind >= PTRWM_TARGET_COUNT) return 0;
   if (proposal_kind < 0 || proposal_kind >= PTRWM_PROPOSAL_COUNT) return 0;
-  const int qi = quad_index_for_dim(dim);
-  if (qi < 0 || n_temps < 1 || n_temps > kQuadMaxTemps) return 0;
-  return quad_variants(target_kind, false).run[proposal_kind][qi] != nullptr ? 1 : 0;
+  const int qi = quad_index_for(dim, n_temps);
+  return qi >= 0 && quad_variants(target_kind, false).run[proposal_kind][qi] != nullptr ? 1 : 0;
 }
 
 int32_t ptrwm_ext_raw_per_step(int32_t proposal_kind, int32_t dim) {
@@ -408,7 +408,9 @@ int32_t ptrwm_has_variant(int32_t target_kind, int32_t proposal_kind, int32_t di
   if (proposal_kind < 0 || proposal_kind >= PTRWM_PROPOSAL_COUNT) return 0;
   const int dpi = width_index_for_dim(dim);
   if (dim < 1 || dpi < 0) return 0;
-  return target_variants(target_kind).run(proposal_kind, dpi) != nullptr ? 1 : 0;
+  if (target_variants(target_kind).run(proposal_kind, dpi) != nullptr) return 1;
+  const int qi = quad_index_for(dim, 1);  // above width 64 the lane-split kernel is the fused kernel
+  return qi >= 0 && quad_variants(target_kind, false).run[proposal_kind][qi] != nullptr ? 1 : 0;
 }
 
 int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *proposal, const ptrwm_run_args *args,
@@ -436,15 +438,14 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   const int dpi = width_index_for_dim(target->dim);
   if (dpi < 0) return PTRWM_E_DIM;
   const bool two_term = target->kind == PTRWM_TARGET_ROUGH_CARPET && rough_carpet_two_term(target->p);
-  RunLaunchFn fn = target_variants(target->kind, two_term).run(proposal->kind, dpi);
-  if (fn == nullptr) return PTRWM_E_NOVARIANT;
-  // lane-split form? (bit-identical results: a speed decision, see g_kernel_form)
+  RunLaunchFn fn = target_variants(target->kind, two_term).run(proposal->kind, dpi);  // null above width 64
+  // lane-split form? (bit-identical results: a speed decision, see g_kernel_form - except above dim 64, where it is the
+  // only form)
   bool quad = false;
   {
-    const int qi = quad_index_for_dim(target->dim);
-    const RunLaunchFn qfn = (qi >= 0 && args->n_temps <= kQuadMaxTemps)
-                                ? quad_variants(target->kind, two_term).run[proposal->kind][qi] : nullptr;
-    if (qfn != nullptr && g_kernel_form != PTRWM_FORM_THREAD) {
+    const int qi = quad_index_for(target->dim, args->n_temps);
+    const RunLaunchFn qfn = qi >= 0 ? quad_variants(target->kind, two_term).run[proposal->kind][qi] : nullptr;
+    if (qfn != nullptr && (fn == nullptr || g_kernel_form != PTRWM_FORM_THREAD)) {
       const long long cpw1 = args->n_temps > 64 ? 1 : 64 / args->n_temps;
       const long long waves1 = args->n_temps > 64 ? args->n_chains * ((args->n_temps + 63) / 64)
                                                   : (args->n_chains + cpw1 - 1) / cpw1;
@@ -452,15 +453,13 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
       bool faster;
       if (target->dim <= 32)
         faster = args->n_temps <= 16 ? w < 1.6 : w < 1.0;
-      else if (target->dim <= 64)
-        faster = w < 0.75 || (target->dim >= 60 && args->n_temps <= 64);
       else
-        faster = args->n_temps <= 64;
-      quad = g_kernel_form == PTRWM_FORM_QUAD || faster;
+        faster = w < 0.75 || (target->dim >= 60 && args->n_temps <= 64);
+      quad = fn == nullptr || g_kernel_form == PTRWM_FORM_QUAD || faster;
       if (quad) fn = qfn;
     }
   }
-
+  if (fn == nullptr) return PTRWM_E_NOVARIANT;
   const long long se = args->swap_every;
   const bool full = ext || args->trace != nullptr || args->accept_flags != nullptr;
   // swap events before step_counter sc = multiples m*se with burn_in < m*se <= sc

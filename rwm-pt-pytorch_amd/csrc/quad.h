@@ -16,7 +16,8 @@
 //
 // Thread map.  slot = tid / 4 (replica within the exchange group), q = tid % 4.  4 T <= 64 ("narrow", T <= 16): an
 // exchange group is one wavefront holding 16 / T whole ladders; a workgroup is four independent wavefronts.
-// 16 < T <= 128 ("wide"): one ladder per workgroup of 4 T threads (rounded up to whole waves, <= 512), barriers for swaps.
+// T > 16 ("wide"): one ladder per workgroup of 4 T threads (rounded up to whole waves; <= 512, or <= 1024 for the
+// dim > 64 class), barriers for swaps.
 #pragma once
 #include "kernel.h"
 
@@ -496,14 +497,17 @@ struct QNealFunnel {
 // dynamic LDS bytes of a workgroup: per replica slot a row of up to 4 W floats plus the six words of kernel.h's swap
 // machinery (log-density, swap uniform, outcome; three spare) -> (W + 2) floats per thread
 constexpr unsigned quad_kernel_lds_bytes(int threads, int w) { return (unsigned)(threads * (w + 2)) * 4u; }
-// widest workgroup: one ladder of up to kQuadMaxTemps temperatures (wider ladders run the one-thread-per-replica kernel)
-constexpr int kQuadMaxThreads = 512;
-constexpr int kQuadMaxTemps = kQuadMaxThreads / kQuad;
+// Widest workgroup = one ladder.  Every variant is compiled for workgroups of up to 512 threads (ladders of <= 128
+// temperatures: up to 256 VGPRs, no spills); the W = 28 class (dim > 64), where this is the ONLY form of the fused kernel,
+// is also compiled for 1024 threads (ladders of <= 256 temperatures: 128 VGPRs, a dozen of them spilled).
+constexpr int kQuadThreads = 512;
+constexpr int kQuadThreadsMax = 1024;
 
 // W      lane register width = canonical range width (8 / 16 / 28)
 // DEXACT dim compiled in (0: run-time dim, any value the width class covers)
-template <class Target, class Proposal, int W, int DEXACT, bool FULL>
-__global__ void __launch_bounds__(kQuadMaxThreads) ptrwm_quad_step_kernel(const KArgs a) {
+// MAXT   largest workgroup the variant may be launched with (kQuadThreads or kQuadThreadsMax)
+template <class Target, class Proposal, int W, int DEXACT, int MAXT, bool FULL>
+__global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
   const int T = a.n_temps;
   const int D = DEXACT ? DEXACT : a.dim;
   const int cpw = a.chains_per_wave;  // ladders per exchange group (narrow: 16 / T per wave; wide: 1 per workgroup)

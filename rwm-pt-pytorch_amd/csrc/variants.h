@@ -103,28 +103,44 @@ hipError_t launch_logp(const float *x, float *out, long long n, int D, const TPa
   return hipGetLastError();
 }
 
-// ---- lane-split ("quad") variants (quad.h): X(lane width W, dim compiled in or 0 for a run-time dim) ---------------
+// ---- lane-split ("quad") variants (quad.h): X(lane width W, dim compiled in or 0 for a run-time dim, max threads) ----
 // W is the canonical range width of the dim class (8 / 16 / 28 for dim <= 32 / 64 / 112); the BASELINE dims get a
-// kernel with dim compiled in, every other dim runs the generic kernel of its class.
-#define PTRWM_QUAD_WIDTHS(X) X(8, 0) X(8, 30) X(16, 0) X(16, 50) X(28, 0) X(28, 100)
+// kernel with dim compiled in, every other dim runs the generic kernel of its class.  The W = 28 class (dim > 64) is the
+// only form of the fused kernel there (see PTRWM_WIDTHS_WIDE above) and therefore also exists for 1024-thread workgroups
+// (ladders of 129..256 temperatures).
+#define PTRWM_QUAD_WIDTHS(X)                                                                              \
+  X(8, 0, kQuadThreads) X(8, 30, kQuadThreads) X(16, 0, kQuadThreads) X(16, 50, kQuadThreads) X(28, 0, kQuadThreads) \
+  X(28, 100, kQuadThreads) X(28, 0, kQuadThreadsMax) X(28, 100, kQuadThreadsMax)
 struct QuadWidthInfo {
-  int w, dexact;
+  int w, dexact, max_threads;
 };
-#define PTRWM_X_QINFO(W, E) {W, E},
+#define PTRWM_X_QINFO(W, E, M) {W, E, M},
 constexpr QuadWidthInfo kQuadWidths[] = {PTRWM_QUAD_WIDTHS(PTRWM_X_QINFO)};
 #undef PTRWM_X_QINFO
 constexpr int kNumQuadWidths = (int)(sizeof(kQuadWidths) / sizeof(kQuadWidths[0]));
-#define PTRWM_X_QOK(W, E) static_assert(W == canon_width(4 * W) && (E == 0 || (E <= 4 * W && canon_width(E) == W)), "quad width table");
+#define PTRWM_X_QOK(W, E, M) static_assert(W == canon_width(4 * W) && (E == 0 || (E <= 4 * W && canon_width(E) == W)), "quad width table");
 PTRWM_QUAD_WIDTHS(PTRWM_X_QOK)
 #undef PTRWM_X_QOK
 
-// the kernel with this dim compiled in if there is one, else the generic kernel of the dim's class; -1 if none
-inline int quad_index_for_dim(int dim) {
-  if (dim < 1 || dim > PTRWM_MAX_DIM) return -1;
+// threads of the workgroup a ladder of n_temps temperatures needs in the lane-split form (narrow ladders: 256)
+inline int quad_block_threads(int n_temps) { return 4 * n_temps > 64 ? ((4 * n_temps + 63) & ~63) : kBlockThreads; }
+
+// the kernel with this dim compiled in if there is one, else the generic kernel of the dim's class, in the smallest
+// workgroup class that holds the ladder; -1 if none
+inline int quad_index_for(int dim, int n_temps) {
+  if (dim < 1 || dim > PTRWM_MAX_DIM || n_temps < 1) return -1;
+  const int threads = quad_block_threads(n_temps);
   int best = -1;
   for (int i = 0; i < kNumQuadWidths; ++i) {
-    if (kQuadWidths[i].dexact == dim) return i;
-    if (kQuadWidths[i].dexact == 0 && kQuadWidths[i].w == canon_width(dim)) best = i;
+    const QuadWidthInfo &q = kQuadWidths[i];
+    if (q.w != canon_width(dim) || q.max_threads < threads || (q.dexact != 0 && q.dexact != dim)) continue;
+    if (best < 0) {
+      best = i;
+      continue;
+    }
+    const QuadWidthInfo &b = kQuadWidths[best];
+    // prefer the smaller workgroup class, then the kernel with dim compiled in
+    if (q.max_threads < b.max_threads || (q.max_threads == b.max_threads && q.dexact != 0 && b.dexact == 0)) best = i;
   }
   return best;
 }
@@ -138,13 +154,14 @@ constexpr int quad_min_own(int w, int dexact) {
   return dexact == 0 ? 0 : (dexact - 3 * w <= 0 ? 0 : (dexact - 3 * w > w ? w : dexact - 3 * w));
 }
 
-template <class Target, class Proposal, int W, int DEXACT>
+template <class Target, class Proposal, int W, int DEXACT, int MAXT>
 hipError_t launch_run_quad(const KArgs &a, unsigned grid, bool full, hipStream_t stream) {
   // narrow ladders (4 T <= 64): four independent one-wave groups per workgroup; wide ones: one ladder per workgroup
-  const unsigned block = 4 * a.n_temps > 64 ? (unsigned)((4 * a.n_temps + 63) & ~63) : (unsigned)kBlockThreads;
+  const unsigned block = (unsigned)quad_block_threads(a.n_temps);
+  if ((int)block > MAXT) return hipErrorInvalidConfiguration;
   const unsigned lds = quad_kernel_lds_bytes((int)block, W);
-  auto kfull = ptrwm_quad_step_kernel<Target, Proposal, W, DEXACT, true>;
-  auto kprod = ptrwm_quad_step_kernel<Target, Proposal, W, DEXACT, false>;
+  auto kfull = ptrwm_quad_step_kernel<Target, Proposal, W, DEXACT, MAXT, true>;
+  auto kprod = ptrwm_quad_step_kernel<Target, Proposal, W, DEXACT, MAXT, false>;
   if (lds > 48u * 1024u) {  // raise the dynamic-LDS allowance once per kernel and device (see launch_run)
     constexpr int kMaxDevices = 64;
     static unsigned long long raised_mask = 0;
@@ -152,7 +169,7 @@ hipError_t launch_run_quad(const KArgs &a, unsigned grid, bool full, hipStream_t
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     const bool known = dev >= 0 && dev < kMaxDevices;
     if (!known || !((__atomic_load_n(&raised_mask, __ATOMIC_ACQUIRE) >> dev) & 1ull)) {
-      const int cap = (int)quad_kernel_lds_bytes(kQuadMaxThreads, W);
+      const int cap = (int)quad_kernel_lds_bytes(MAXT, W);
       hipError_t e = hipFuncSetAttribute((const void *)kfull, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void *)kprod, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
       if (e != hipSuccess) return e;
@@ -166,9 +183,9 @@ hipError_t launch_run_quad(const KArgs &a, unsigned grid, bool full, hipStream_t
   return hipGetLastError();
 }
 
-#define PTRWM_X_QRUN_N(W, E) launch_run_quad<QTGT<W, quad_min_own(W, E)>, QNormal<W, quad_min_own(W, E)>, W, E>,
-#define PTRWM_X_QRUN_L(W, E) launch_run_quad<QTGT<W, quad_min_own(W, E)>, QLaplace<W, quad_min_own(W, E)>, W, E>,
-#define PTRWM_X_QRUN_U(W, E) launch_run_quad<QTGT<W, quad_min_own(W, E)>, QUniformRadius<W, quad_min_own(W, E)>, W, E>,
+#define PTRWM_X_QRUN_N(W, E, M) launch_run_quad<QTGT<W, quad_min_own(W, E)>, QNormal<W, quad_min_own(W, E)>, W, E, M>,
+#define PTRWM_X_QRUN_L(W, E, M) launch_run_quad<QTGT<W, quad_min_own(W, E)>, QLaplace<W, quad_min_own(W, E)>, W, E, M>,
+#define PTRWM_X_QRUN_U(W, E, M) launch_run_quad<QTGT<W, quad_min_own(W, E)>, QUniformRadius<W, quad_min_own(W, E)>, W, E, M>,
 // One translation unit per target (csrc/quad_<target>.hip) defines its table with this macro.
 #define PTRWM_DEFINE_QUAD_VARIANTS(SYMBOL, QTARGET)                        \
   template <int W, int M>                                                  \
@@ -190,6 +207,16 @@ hipError_t launch_run_quad(const KArgs &a, unsigned grid, bool full, hipStream_t
 #ifdef PTRWM_PART_WIDE
 #define PTRWM_PART_SUFFIX(SYMBOL) SYMBOL##_wide
 #define PTRWM_PART_ROW(X) PTRWM_WIDTHS_NARROW(PTRWM_X_NULL) PTRWM_WIDTHS_WIDE(X)
+// No one-thread-per-replica STEP kernels above width 64 (they needed 340-420 VGPRs, i.e. AGPR copies next to ~150 spilled
+// SGPRs: the regime in which hipcc produced wrong code twice - round 1 under max-ILP scheduling, round 2 under the default
+// scheduler after a fence moved; profiles/r02_miscompile_width80.txt): dim > 64 always runs the lane-split kernel
+// (<= 256 VGPRs, no AGPRs).  The wide objects keep the stand-alone log-density kernels (121 VGPRs).
+#undef PTRWM_X_RUN_N
+#undef PTRWM_X_RUN_L
+#undef PTRWM_X_RUN_U
+#define PTRWM_X_RUN_N(W, E) nullptr,
+#define PTRWM_X_RUN_L(W, E) nullptr,
+#define PTRWM_X_RUN_U(W, E) nullptr,
 #else
 #define PTRWM_PART_SUFFIX(SYMBOL) SYMBOL##_narrow
 #define PTRWM_PART_ROW(X) PTRWM_WIDTHS_NARROW(X) PTRWM_WIDTHS_WIDE(PTRWM_X_NULL)
