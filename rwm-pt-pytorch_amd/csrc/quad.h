@@ -654,8 +654,34 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
       s_l[slot_raw] = my_l;  // the four lanes of a quad write the same value
       s_u[slot_raw] = us;
       sync_group();
-      swap_decide(T, t, base, slot, a.swap_mode, a.swap_order, (ev_par0 + swap_in_call) & 1, a.beta, beta_t, us, s_l, s_u,
-                  s_landed, my_l, src, pair_acc);
+      if (wide && a.swap_order == PTRWM_ORDER_SEQUENTIAL && a.swap_mode == PTRWM_SWAP_EXCHANGE) {
+        // A wide ladder spans several wavefronts; the sequential sweep (kernel.h swap_decide: a scan over the ladder's
+        // published values that every thread replays) would be replayed by every one of them - four times the work per
+        // ladder of the one-thread-per-replica kernel.  Here the first wavefront alone runs the scan and publishes, for
+        // every position, the slot whose vector lands there; a barrier later everyone picks up its own position.  Same
+        // decisions, same values (the scan code is swap_decide's).
+        if (threadIdx.x < 64) {
+          float car_l = s_l[0];
+          int car_i = 0;
+#pragma unroll 2
+          for (int j = 0; j < T - 1; ++j) {
+            const float lk = s_l[j + 1];
+            const float u = s_u[j];
+            const bool ok = swap_accept_test(u, swap_log_prob(a.beta[j], a.beta[j + 1], car_l, lk));
+            s_landed[j] = ok ? j + 1 : car_i;
+            car_l = ok ? car_l : lk;
+            car_i = ok ? car_i : j + 1;
+          }
+          s_landed[T - 1] = car_i;
+        }
+        __syncthreads();
+        src = s_landed[base + t];
+        my_l = s_l[src];
+        pair_acc = (t < T - 1) && (src == base + t + 1);
+      } else {
+        swap_decide(T, t, base, slot, a.swap_mode, a.swap_order, (ev_par0 + swap_in_call) & 1, a.beta, beta_t, us, s_l, s_u,
+                    s_landed, my_l, src, pair_acc);
+      }
       if (pair_acc) {
         n_swap_acc += 1;
         last_event = swap_in_call;
