@@ -322,10 +322,13 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
         return 0.0 if self._run is None else self._sq_beta_jumps()
 
     def _stat_denominator(self) -> int:
-        """One ladder: the attempt count at the last accepted swap (what the reference's refresh-on-accept
-        leaves behind).  Several ladders: all attempts."""
-        if self.num_replicas == 1 and self._run.swap_order == ptrwm_hip.ORDER_SEQUENTIAL:
-            return int(self._run.last_ord.max().item())
+        """The reference refreshes `swap_acceptance_rate` / `pt_esjd` only when a swap is accepted (:627-633), so what
+        it reports is accepted / (attempt count AT THE LAST ACCEPTED SWAP).  With the sequential sweep every ladder
+        records that ordinal; the denominator is their sum over the ladders - for one ladder exactly the reference's
+        number, for many the same statistic pooled (no jump when `num_replicas` goes from 1 to 2).  Even/odd events have
+        a varying pair count per event: all attempts are used there."""
+        if self._run.swap_order == ptrwm_hip.ORDER_SEQUENTIAL:
+            return int(self._run.last_ord.max(dim=1).values.sum().item())
         return self.num_swap_attempts
 
     @property

@@ -252,6 +252,24 @@ def test_pt_reference_run_through_the_class(device):
     assert alg.pt_esjd == pytest.approx(alg.squared_jump_distances / last)
 
 
+def test_swap_statistics_pool_over_ladders_without_a_jump(device):
+    """`swap_acceptance_rate` / `pt_esjd` keep the reference's refresh-on-accept meaning (accepted / attempt count at the
+    last accepted swap, pt_rwm_gpu_optimized.py:627-633) for any number of ladders: each ladder contributes its own
+    ordinal, so one ladder of a three-ladder run reports what it reports alone."""
+    target = RoughCarpetDistributionTorch(10, device=device, mode_centers=[-15.0, 0.0, 15.0])
+    kw = dict(beta_ladder=[1.0, 0.5, 0.2, 0.05], swap_every=7, burn_in=3, device=device, seed=12, trace="none")
+    three = ParallelTemperingRWM_GPU_Optimized(10, 0.5, target, num_replicas=3, **kw)
+    three._advance(500)
+    ords = three._run.last_ord.max(dim=1).values
+    assert three.swap_acceptance_rate == pytest.approx(three.num_swap_acceptances / int(ords.sum()))
+    assert three.pt_esjd == pytest.approx(three.squared_jump_distances / int(ords.sum()))
+    one = ParallelTemperingRWM_GPU_Optimized(10, 0.5, target, num_replicas=1, **kw)  # = ladder 0 of `three`
+    one._advance(500)
+    assert torch.equal(one._run.last_ord[0], three._run.last_ord[0])
+    assert one.swap_acceptance_rate == pytest.approx(int(three._run.swap_accept[0].sum()) / int(ords[0]))
+    assert int(ords.sum()) <= three.num_swap_attempts
+
+
 def test_pt_iterative_ladder_on_device(device):
     """Iterative (Robbins-Monro) ladder: adjacent estimated swap rates land near the 0.234 target."""
     torch.manual_seed(5)
