@@ -22,7 +22,8 @@ struct VariantPair {
 // pins it for tests and tuning.  AUTO follows the measured crossover (profiles/r02_form_sweep.txt, both forms timed over
 // batch sizes, ladder lengths and dims on one MI355X).  w = wavefronts per SIMD the one-thread-per-replica kernel would
 // launch:
-//   dim <= 32        lane-split when w < 1.6 (ladders of <= 16 temperatures) or w < 1.0 (longer ladders): a lone wave
+//   dim < 16         never (profiles/r02_single_ladder.txt)
+//   16 <= dim <= 32  lane-split when w < 1.6 (ladders of <= 16 temperatures) or w < 1.0 (longer ladders): a lone wave
 //                    issues one VALU instruction per ~5 cycles instead of ~3.4, and below one wave per SIMD the split
 //                    puts four times as many SIMDs to work (2.5-3.2x for a single ladder)
 //   32 < dim <= 64   the four lanes own 16 dims each, so dims well below 64 waste lanes (dim 50: 28 %): lane-split when
@@ -451,7 +452,10 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
                                                   : (args->n_chains + cpw1 - 1) / cpw1;
       const double w = (double)waves1 / (double)kSimds;
       bool faster;
-      if (target->dim <= 32)
+      if (target->dim < 16)
+        faster = false;  // a lane would own <= 3 dims and most of the quad one Philox block: the thread kernels (dim
+                         // compiled in for 2, 3, 4, 5, 10) are 1.3-1.8x faster even for a single ladder
+      else if (target->dim <= 32)
         faster = args->n_temps <= 16 ? w < 1.6 : w < 1.0;
       else
         faster = w < 0.75 || (target->dim >= 60 && args->n_temps <= 64);

@@ -109,8 +109,8 @@ hipError_t launch_logp(const float *x, float *out, long long n, int D, const TPa
 // only form of the fused kernel there (see PTRWM_WIDTHS_WIDE above) and therefore also exists for 1024-thread workgroups
 // (ladders of 129..256 temperatures).
 #define PTRWM_QUAD_WIDTHS(X)                                                                              \
-  X(8, 0, kQuadThreads) X(8, 30, kQuadThreads) X(16, 0, kQuadThreads) X(16, 50, kQuadThreads) X(28, 0, kQuadThreads) \
-  X(28, 100, kQuadThreads) X(28, 0, kQuadThreadsMax) X(28, 100, kQuadThreadsMax)
+  X(8, 0, kQuadThreads) X(8, 20, kQuadThreads) X(8, 30, kQuadThreads) X(16, 0, kQuadThreads) X(16, 50, kQuadThreads) \
+  X(28, 0, kQuadThreads) X(28, 100, kQuadThreads) X(28, 0, kQuadThreadsMax) X(28, 100, kQuadThreadsMax)
 struct QuadWidthInfo {
   int w, dexact, max_threads;
 };

@@ -793,6 +793,41 @@ def test_long_run_statistics_match_the_reference_anchors(device):
     check("pt cold esjd", cold.mean(), cold.std(ddof=1) / np.sqrt(lad), ref["pt"]["cold_esjd"])
 
 
+def test_pt_statistics_against_the_tight_oracle_anchor(device):
+    """The PT statistics at a resolution the reference's own runs cannot give (its cold-chain ESJD anchor is +-0.4 %):
+    tests/golden/oracle_anchor_pt.json holds thousands of independent ladders of the C oracle in Philox mode (the
+    oracle reproduces the reference's trajectories decision for decision on shared randoms, so it samples the same
+    chain; generate_oracle_anchor.py).  The engine on 16 384 ladders over the same horizon: cold-chain ESJD, swap
+    fraction and cold acceptance rate within 1e-3 relative + 4 combined standard errors (each ~3e-4 relative)."""
+    import json
+    import os
+
+    path = os.path.join(H.GOLDEN, "oracle_anchor_pt.json")
+    if not os.path.exists(path):
+        pytest.skip("oracle_anchor_pt.json not generated")
+    with open(path) as f:
+        ref = json.load(f)
+    if ref["n_ladders"] < 1000:
+        pytest.skip("oracle anchor too small to be tighter than the reference anchor")
+    dim, n, burn, lad = 30, ref["steps_per_ladder"], ref["burn_in"], 16384
+    target = RoughCarpetDistributionTorch(dim, device=device, mode_centers=[-15.0, 0.0, 15.0])
+    pt = ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target, beta_ladder=ref["beta_ladder"],
+                                            swap_every=ref["swap_every"], burn_in=burn, device=device, num_replicas=lad,
+                                            seed=31337, swap_mode="reference_copy", trace="none")
+    pt._ensure_started()
+    pt._run.advance(burn + n)
+    attempts = pt._run.swap_attempts_per_replica()
+    got = {"cold_esjd": (pt._run.sq_jump[:, 0] / n).cpu().numpy(),
+           "swap_accept_fraction": (pt._run.swap_accept.sum(1).double() / attempts).cpu().numpy(),
+           "cold_acceptance_rate": (pt._run.n_accept[:, 0].double() / n).cpu().numpy()}
+    for name, v in got.items():
+        a = ref[name]
+        se = v.std(ddof=1) / np.sqrt(lad)
+        tol = 1e-3 * abs(a["mean"]) + 4.0 * (a["stderr"] ** 2 + se ** 2) ** 0.5
+        assert abs(v.mean() - a["mean"]) <= tol, (name, v.mean(), se, a, tol)
+        assert a["stderr"] / abs(a["mean"]) < 1.5e-3 and se / abs(a["mean"]) < 1e-3  # the comparison has teeth
+
+
 @pytest.mark.parametrize("family", ["rwm_tm_uniform", "rwm_even_laplace"])
 def test_long_run_statistics_of_the_other_baseline_families(device, family):
     """The families of BASELINE configs[3] / [4] against the reference's RWM class with `proposal_distribution=`
