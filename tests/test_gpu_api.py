@@ -568,6 +568,26 @@ def test_two_gpu_processes_equal_one(device, tmp_path):
         assert float(p["sum_swap_acceptance_rate"]) == want["swap_acceptance_rate"]
 
 
+def test_sampler_on_a_second_gpu_without_set_device():
+    """a sampler constructed with device='cuda:1' while cuda:0 is the process's current device must launch
+    on cuda:1 (the binding's on_device guard; the library itself never switches devices) and give the bits it gives on
+    cuda:0.  Needs two visible GPUs (skipped on the one-GPU test boxes; the guard's logic is unit-tested on the CPU)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    torch.cuda.set_device(0)
+    outs = []
+    for idx in (0, 1):
+        dev = torch.device("cuda", idx)
+        target = RoughCarpetDistributionTorch(30, device=dev, mode_centers=[-15.0, 0.0, 15.0])
+        alg = ParallelTemperingRWM_GPU_Optimized(30, 2.38**2 / 30, target, beta_ladder=geometric_beta_ladder(130),
+                                                 swap_every=5, burn_in=0, device=dev, num_replicas=4, seed=9, trace="none")
+        alg._advance(40)  # 130 temperatures: > 48 KB of dynamic LDS, raised per device
+        torch.cuda.synchronize(dev)
+        assert torch.cuda.current_device() == 0 and alg._run.state.device == dev
+        outs.append(alg._run.state.cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_second_plan_with_large_lds_on_the_same_process(device):
     """The raised dynamic-LDS allowance (> 48 KB: wide ladders at large dims) is set per device inside the library;
     a process that has already run one such plan must be able to build and run a second, different one (and the
