@@ -185,12 +185,18 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
             # reference layout [temperature, step, dim] as a view
             self.pre_allocated_chains = self._trace[:, 0].permute(1, 0, 2)
             self.pre_allocated_log_densities = self._trace_logp[:, 0].permute(1, 0)
-            self.chain_indices = torch.zeros(T, dtype=torch.long)
         else:
             self._trace = self._trace_logp = None
             self.pre_allocated_chains = self.pre_allocated_log_densities = None
-            self.chain_indices = None
         self._rows_used = 0
+
+    @property
+    def chain_indices(self):
+        """The reference's per-temperature write positions (pt_rwm_gpu_optimized.py:471): every temperature has stored
+        the same number of states, `_rows_used`; built on demand (updating a tensor every step() costs microseconds)."""
+        if getattr(self, "_trace", None) is None:
+            return None
+        return torch.full((len(self.beta_ladder),), self._rows_used, dtype=torch.long)
 
     def _ensure_started(self):
         if self._run is not None:
@@ -208,7 +214,6 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
             self._trace[0, 0] = self._run.state[0, :nt]
             self._trace_logp[0, 0] = self._run.logp[0, :nt]
             self._rows_used = 1
-            self.chain_indices[:] = 1
 
     def _advance(self, n_steps: int):
         self._ensure_started()
@@ -224,17 +229,14 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
                     self._trace[:used] = old[:used]
                     self._trace_logp[:used] = old_lp[:used]
                     self._rows_used = used
-                    self.chain_indices[:] = used
                 else:
                     nt = self._trace.shape[2]
                     self._trace[0, 0] = self._run.state[0, :nt]
                     self._trace_logp[0, 0] = self._run.logp[0, :nt]
                     self._rows_used = 1
-                    self.chain_indices[:] = 1
             self._run.advance(n_steps, trace=self._trace, trace_logp=self._trace_logp, trace_row0=self._rows_used,
                               trace_every=self.thin)
             self._rows_used += rows
-            self.chain_indices[:] = self._rows_used
         else:
             self._run.advance(n_steps)
         self.step_counter += n_steps
@@ -250,8 +252,6 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
         self._chain_cache = None
         self.current_states = self.current_log_densities = None
         self._rows_used = 0
-        if self.chain_indices is not None:
-            self.chain_indices[:] = 0
 
     def step(self, step_index: int = None):
         """All temperatures take one MH step; swaps follow when due (one fused launch, n_steps = 1)."""

@@ -414,6 +414,7 @@ class RunPlan:
         self._refs = (self._t, self._p, C.byref(self._t) if target is not None else None, C.byref(self._p), C.byref(a))
         self._keep = (target, proposal, state, logp, beta, n_accept, sq_jump, swap_accept, last_swap_ordinal)
         self._plain = True  # no per-launch buffers set in _a
+        self._last_trace = (None, None, None)  # (trace, trace_logp, trace_every) marshalled into _a by the last launch
         self._guard = on_device(self.device)  # (after the checks above: they reject CPU tensors first)
 
     def launch(
@@ -440,7 +441,18 @@ class RunPlan:
         a.swap_event_offset = swap_event_offset
         plain = (ext_prop is None and ext_u is None and ext_swap_u is None and trace is None and trace_logp is None
                  and accept_flags is None)
-        if not (plain and self._plain):
+        # trace-only launches into the SAME buffers as the previous launch (the reference's step()-at-a-time pattern with
+        # chain storage): only the row offset moves - skip re-marshalling (a dozen ctypes field stores, ~4 us)
+        same_trace = (trace is not None and trace is self._last_trace[0] and trace_logp is self._last_trace[1]
+                      and trace_every == self._last_trace[2] and ext_prop is None and ext_u is None and ext_swap_u is None
+                      and accept_flags is None)
+        if same_trace:
+            te = a.trace_every
+            if trace.shape[0] < trace_row0 + ((step0 + n_steps) // te - step0 // te):
+                raise ValueError("trace must be [rows >= trace_row0 + traced steps, trace_chains, trace_temps, dim]")
+            a.trace_row0 = trace_row0
+        elif not (plain and self._plain):
+            self._last_trace = (None, None, None)
             Cn, T, D = self.shape
             a.ext_prop = _opt(ext_prop, "ext_prop", torch.float32)
             a.ext_u = _opt(ext_u, "ext_u", torch.float32)
@@ -466,6 +478,8 @@ class RunPlan:
                 raise ValueError("accept_flags must be [n_steps, n_chains, n_temps]")
             a.accept_flags = _opt(accept_flags, "accept_flags", torch.uint8)
             self._plain = plain
+            if trace is not None and ext_prop is None and ext_u is None and ext_swap_u is None and accept_flags is None:
+                self._last_trace = (trace, trace_logp, trace_every)
         with self._guard:
             rc = self._lib.ptrwm_run(self._refs[2], self._refs[3], self._refs[4], _stream(self.device))
         if rc != 0:
@@ -487,6 +501,7 @@ class RunPlan:
         Cn, T, D = self.shape
         props, acc_u = self._split_buffers()
         a.step0 = step
+        self._last_trace = (None, None, None)
         a.ext_prop = _opt(ext_prop, "ext_prop", torch.float32)
         a.ext_u = _opt(ext_u, "ext_u", torch.float32)
         if ext_prop is not None:
@@ -516,6 +531,7 @@ class RunPlan:
             raise ValueError(f"accept_flags of one step must be [{Cn}, {T}]")
         a.step0 = step
         a.swap_event_offset = swap_event_offset
+        self._last_trace = (None, None, None)
         a.ext_swap_u = _opt(ext_swap_u, "ext_swap_u", torch.float32)
         a.accept_flags = _opt(accept_flags, "accept_flags", torch.uint8)
         self._plain = False
@@ -536,6 +552,7 @@ class RunPlan:
         if ext_swap_u is not None and tuple(ext_swap_u.shape) != (Cn, T - 1):
             raise ValueError(f"ext_swap_u must be [{Cn}, {T - 1}]")
         a.step0 = rng_step
+        self._last_trace = (None, None, None)
         a.ext_swap_u = _opt(ext_swap_u, "ext_swap_u", torch.float32)
         self._plain = False  # per-launch fields of _a were touched: the next launch() rewrites them
         with self._guard:
