@@ -31,7 +31,7 @@ struct VariantPair {
 //   dim > 64         lane-split always: it is the only form there (the one-thread-per-replica kernel needed 340-420
 //                    VGPRs - one wave per SIMD, 8-25 % slower at full batches, 1.8x at small ones - and sat in the
 //                    register regime in which hipcc miscompiled it twice; see variants.h)
-static int g_kernel_form = PTRWM_FORM_AUTO;
+static int g_kernel_form = PTRWM_FORM_AUTO;  // read / written with __atomic builtins (ptrwm_set_kernel_form may race with a launch)
 constexpr long long kSimds = 1024;  // 256 CUs x 4
 
 static const QuadVariants &quad_variants(int kind, bool two_term) {
@@ -383,9 +383,7 @@ const char *ptrwm_strerror(int32_t code) {
 
 int32_t ptrwm_set_kernel_form(int32_t form) {
   if (form != PTRWM_FORM_AUTO && form != PTRWM_FORM_THREAD && form != PTRWM_FORM_QUAD) return PTRWM_E_ARG;
-  const int32_t prev = g_kernel_form;
-  g_kernel_form = form;
-  return prev;
+  return __atomic_exchange_n(&g_kernel_form, form, __ATOMIC_RELAXED);
 }
 
 int32_t ptrwm_has_quad_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim, int32_t n_temps) {
@@ -446,7 +444,8 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   {
     const int qi = quad_index_for(target->dim, args->n_temps);
     const RunLaunchFn qfn = qi >= 0 ? quad_variants(target->kind, two_term).run[proposal->kind][qi] : nullptr;
-    if (qfn != nullptr && (fn == nullptr || g_kernel_form != PTRWM_FORM_THREAD)) {
+    const int form = __atomic_load_n(&g_kernel_form, __ATOMIC_RELAXED);
+    if (qfn != nullptr && (fn == nullptr || form != PTRWM_FORM_THREAD)) {
       const long long cpw1 = args->n_temps > 64 ? 1 : 64 / args->n_temps;
       const long long waves1 = args->n_temps > 64 ? args->n_chains * ((args->n_temps + 63) / 64)
                                                   : (args->n_chains + cpw1 - 1) / cpw1;
@@ -459,7 +458,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
         faster = args->n_temps <= 16 ? w < 1.6 : w < 1.0;
       else
         faster = w < 0.75 || (target->dim >= 60 && args->n_temps <= 64);
-      quad = fn == nullptr || g_kernel_form == PTRWM_FORM_QUAD || faster;
+      quad = fn == nullptr || form == PTRWM_FORM_QUAD || faster;
       if (quad) fn = qfn;
     }
   }

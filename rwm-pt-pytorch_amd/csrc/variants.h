@@ -63,6 +63,22 @@ struct TargetVariants {
   LogpLaunchFn logp[kNumWidths];
 };
 
+// Raises the dynamic-LDS allowance of a kernel pair (fixture + production variant) to `cap` bytes: once per kernel AND
+// per device (the attribute belongs to the function object of the device that is current when it is set; a process
+// that samples on cuda:0 and later on cuda:1 must raise it on both).  `raised_mask` is the caller's per-kernel static.
+inline hipError_t raise_dynamic_lds(const void *kfull, const void *kprod, int cap, unsigned long long &raised_mask) {
+  constexpr int kMaxDevices = 64;  // bit d: raised on device d (a race merely sets the attribute twice)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+  const bool known = dev >= 0 && dev < kMaxDevices;
+  if (known && ((__atomic_load_n(&raised_mask, __ATOMIC_ACQUIRE) >> dev) & 1ull)) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(kfull, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  if (e == hipSuccess) e = hipFuncSetAttribute(kprod, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  if (e != hipSuccess) return e;
+  if (known) __atomic_fetch_or(&raised_mask, 1ull << dev, __ATOMIC_RELEASE);
+  return hipSuccess;
+}
+
 template <class Target, class Proposal, int DP, bool EXACT>
 hipError_t launch_run(const KArgs &a, unsigned grid, bool full, hipStream_t stream) {
   // narrow ladders: four independent one-wave groups per workgroup; wide ones (n_temps > 64): as many waves as
@@ -71,22 +87,11 @@ hipError_t launch_run(const KArgs &a, unsigned grid, bool full, hipStream_t stre
   const unsigned lds = step_kernel_lds_bytes((int)block, DP);
   auto kfull = ptrwm_step_kernel<Target, Proposal, DP, EXACT, true>;
   auto kprod = ptrwm_step_kernel<Target, Proposal, DP, EXACT, false>;
-  if (lds > 48u * 1024u) {
-    // above the default dynamic-LDS allowance (wide ladders at large dim): raise it once per kernel AND per device
-    // (the attribute belongs to the function object of the device that is current when it is set; a process that
-    // samples on cuda:0 and later on cuda:1 must raise it on both)
-    constexpr int kMaxDevices = 64;
-    static unsigned long long raised_mask = 0;  // bit d: raised on device d (a race merely sets the attribute twice)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
-    const bool known = dev >= 0 && dev < kMaxDevices;
-    if (!known || !((__atomic_load_n(&raised_mask, __ATOMIC_ACQUIRE) >> dev) & 1ull)) {
-      const int cap = (int)step_kernel_lds_bytes(kBlockThreads, DP);
-      hipError_t e = hipFuncSetAttribute((const void *)kfull, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)kprod, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-      if (e != hipSuccess) return e;
-      if (known) __atomic_fetch_or(&raised_mask, 1ull << dev, __ATOMIC_RELEASE);
-    }
+  if (lds > 48u * 1024u) {  // above the default dynamic-LDS allowance (wide ladders at large dim)
+    static unsigned long long raised_mask = 0;
+    const hipError_t e = raise_dynamic_lds((const void *)kfull, (const void *)kprod,
+                                           (int)step_kernel_lds_bytes(kBlockThreads, DP), raised_mask);
+    if (e != hipSuccess) return e;
   }
   if (full)
     hipLaunchKernelGGL(kfull, dim3(grid), dim3(block), lds, stream, a);
@@ -162,19 +167,11 @@ hipError_t launch_run_quad(const KArgs &a, unsigned grid, bool full, hipStream_t
   const unsigned lds = quad_kernel_lds_bytes((int)block, W);
   auto kfull = ptrwm_quad_step_kernel<Target, Proposal, W, DEXACT, MAXT, true>;
   auto kprod = ptrwm_quad_step_kernel<Target, Proposal, W, DEXACT, MAXT, false>;
-  if (lds > 48u * 1024u) {  // raise the dynamic-LDS allowance once per kernel and device (see launch_run)
-    constexpr int kMaxDevices = 64;
+  if (lds > 48u * 1024u) {
     static unsigned long long raised_mask = 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
-    const bool known = dev >= 0 && dev < kMaxDevices;
-    if (!known || !((__atomic_load_n(&raised_mask, __ATOMIC_ACQUIRE) >> dev) & 1ull)) {
-      const int cap = (int)quad_kernel_lds_bytes(MAXT, W);
-      hipError_t e = hipFuncSetAttribute((const void *)kfull, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)kprod, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-      if (e != hipSuccess) return e;
-      if (known) __atomic_fetch_or(&raised_mask, 1ull << dev, __ATOMIC_RELEASE);
-    }
+    const hipError_t e = raise_dynamic_lds((const void *)kfull, (const void *)kprod,
+                                           (int)quad_kernel_lds_bytes(MAXT, W), raised_mask);
+    if (e != hipSuccess) return e;
   }
   if (full)
     hipLaunchKernelGGL(kfull, dim3(grid), dim3(block), lds, stream, a);
