@@ -279,6 +279,18 @@ def main():
                     100, 2.38**2 / 100, RoughCarpetDistributionTorch(100, device=dev, mode_centers=[-15.0, 0.0, 15.0]),
                     beta_ladder=geometric_beta_ladder(T), swap_every=args.swap_every, burn_in=0, device=dev,
                     num_replicas=C, seed=42, trace="none"), max(50, args.inner // 10), n=3),
+            "configs[3] per-GPU shard: EvenRosenbrock dim 30, Laplace proposal, 32 temps, 65536 ladders": quick(
+                lambda: ParallelTemperingRWM_GPU_Optimized(
+                    30, 2.38**2 / 30, EvenRosenbrockTorch(30, device=dev), beta_ladder=geometric_beta_ladder(32),
+                    swap_every=args.swap_every, burn_in=0, device=dev, num_replicas=65536, seed=42, trace="none",
+                    proposal_distribution=LaplaceProposal(30, torch.full((30,), 0.004), 1.0, dev, torch.float32)),
+                max(50, args.inner // 4), n=3),
+            "configs[4] per-GPU shard: ThreeMixture dim 50, UniformRadius proposal, 64 temps, 131072 ladders": quick(
+                lambda: ParallelTemperingRWM_GPU_Optimized(
+                    50, 2.38**2 / 50, ThreeMixtureDistributionTorch(50, device=dev), beta_ladder=geometric_beta_ladder(64),
+                    swap_every=args.swap_every, burn_in=0, device=dev, num_replicas=131072, seed=42, trace="none",
+                    proposal_distribution=UniformRadiusProposal(50, 2.4, 1.0, dev, torch.float32)),
+                max(50, args.inner // 10), n=3),
             "configs[2] with swap_order=even_odd": quick(
                 lambda: ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target,
                                                            beta_ladder=geometric_beta_ladder(T),

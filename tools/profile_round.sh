@@ -1,7 +1,8 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun -- 'bash tools/profile_round.sh r02'): rocprofv3 kernel-trace stats and the PMC passes of
 # the default bench command (BASELINE configs[2], the headline), of the same workload with ONE Metropolis step per launch
-# (the HBM-streaming formulation) and of BASELINE configs[1] (RWM, one temperature); raw output under
+# (the HBM-streaming formulation), of BASELINE configs[1] (RWM, one temperature) and of the per-GPU shards of configs[3] /
+# configs[4]; raw output under
 # gpurun_out/prof_<tag>/; tools/profile_summary.py then writes the summaries under profiles/.  Counters are collected
 # in their own runs (one TCC counter per pass), never together with API tracing; the program after `--` is python3 itself.
 set -e
@@ -24,6 +25,8 @@ prof() {  # prof <name> <kernel-trace steps> <pmc steps> <bench args...>
 prof cfg3 20 4
 prof cfg3_inner1 200 40 --inner 1
 prof cfg2 20 4 --workload cfg2
+prof cfg4 10 3 --workload cfg4 --inner 500
+prof cfg5 10 3 --workload cfg5 --inner 200
 cd /root/repo
 timeout -k 10 500 python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 echo "bench done"

@@ -27,6 +27,8 @@ CFGS = {
     "cfg3": ("pt_d30_T32_C65536", None, "BASELINE configs[2]: 65536 ladders x 32 temps", 3),
     "cfg3_inner1": ("pt_d30_T32_C65536_inner1", 1, "BASELINE configs[2], ONE Metropolis step per launch", 3),
     "cfg2": ("rwm_d30_T1_C65536", None, "BASELINE configs[1]: 65536 chains x 1 temperature", 3),
+    "cfg4": ("cfg4", 500, "BASELINE configs[3] per-GPU shard: EvenRosenbrock d30, Laplace, 32 temps, 65536 ladders, 500 steps per launch", 3),
+    "cfg5": ("cfg5", 200, "BASELINE configs[4] per-GPU shard: ThreeMixture d50, UniformRadius, 64 temps, 131072 ladders, 200 steps per launch", 3),
 }
 
 
