@@ -493,7 +493,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   // exchange groups: one wavefront holding whole ladders, or ("wide") one workgroup per ladder
   const int lanes_per_replica = quad ? kQuad : 1;
   const bool wide = args->n_temps * lanes_per_replica > 64;
-  k.chains_per_wave = wide ? 1 : 64 / (args->n_temps * lanes_per_replica);
+  k.chains_per_wave = quad ? quad_ladders_per_group(args->n_temps) : (wide ? 1 : 64 / args->n_temps);
   k.k0 = (unsigned)(args->seed & 0xffffffffull);
   k.k1 = (unsigned)(args->seed >> 32);
   k.tp = make_tparams(target);
@@ -506,7 +506,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   k.full.n_raw_ext = ptrwm_ext_raw_per_step(proposal->kind, target->dim);
 
   const long long n_waves = (args->n_chains + k.chains_per_wave - 1) / k.chains_per_wave;
-  const long long n_blocks = wide ? args->n_chains : (n_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+  const long long n_blocks = wide ? n_waves : (n_waves + kWavesPerBlock - 1) / kWavesPerBlock;  // wide: one group per block
   if (n_blocks > 0x7fffffffll) return PTRWM_E_ARG;
 
   // One launch covers a bounded amount of work (32-bit in-kernel counters; no multi-second kernels on a shared

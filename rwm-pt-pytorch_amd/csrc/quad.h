@@ -16,8 +16,8 @@
 //
 // Thread map.  slot = tid / 4 (replica within the exchange group), q = tid % 4.  4 T <= 64 ("narrow", T <= 16): an
 // exchange group is one wavefront holding 16 / T whole ladders; a workgroup is four independent wavefronts.
-// T > 16 ("wide"): one ladder per workgroup of 4 T threads (rounded up to whole waves; <= 512, or <= 1024 for the
-// dim > 64 class), barriers for swaps.
+// T > 16 ("wide"): the exchange group is the workgroup - as many whole ladders as fill 256 threads best, or one ladder in
+// 4 T threads rounded up to whole waves (<= 512, or <= 1024 for the dim > 64 class); barriers for swaps.
 #pragma once
 #include "kernel.h"
 
@@ -510,10 +510,10 @@ template <class Target, class Proposal, int W, int DEXACT, int MAXT, bool FULL>
 __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
   const int T = a.n_temps;
   const int D = DEXACT ? DEXACT : a.dim;
-  const int cpw = a.chains_per_wave;  // ladders per exchange group (narrow: 16 / T per wave; wide: 1 per workgroup)
-  const bool wide = 4 * T > 64;       // grid-uniform
+  const int cpw = a.chains_per_wave;  // ladders per exchange group (narrow: 16 / T per wave; wide: per workgroup)
+  const bool wide = 4 * T > 64;       // grid-uniform: the exchange group is the whole workgroup
   const int tid = wide ? (int)threadIdx.x : (int)(threadIdx.x & 63);
-  const int gthreads = wide ? ((4 * T + 63) & ~63) : 64;
+  const int gthreads = wide ? (int)blockDim.x : 64;
   const int nslots = gthreads >> 2;
   const long long chain0 =
       (wide ? (long long)blockIdx.x : (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * cpw;
@@ -657,22 +657,23 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
       if (wide && a.swap_order == PTRWM_ORDER_SEQUENTIAL && a.swap_mode == PTRWM_SWAP_EXCHANGE) {
         // A wide ladder spans several wavefronts; the sequential sweep (kernel.h swap_decide: a scan over the ladder's
         // published values that every thread replays) would be replayed by every one of them - four times the work per
-        // ladder of the one-thread-per-replica kernel.  Here the first wavefront alone runs the scan and publishes, for
-        // every position, the slot whose vector lands there; a barrier later everyone picks up its own position.  Same
+        // ladder of the one-thread-per-replica kernel.  Here ONE lane per ladder runs the scan and publishes, for every
+        // position, the slot whose vector lands there; a barrier later everyone picks up its own position.  Same
         // decisions, same values (the scan code is swap_decide's).
-        if (threadIdx.x < 64) {
-          float car_l = s_l[0];
-          int car_i = 0;
+        if ((int)threadIdx.x < cpw) {  // lane i of the first wavefront scans ladder i of the workgroup
+          const int b0 = (int)threadIdx.x * T;
+          float car_l = s_l[b0];
+          int car_i = b0;
 #pragma unroll 2
           for (int j = 0; j < T - 1; ++j) {
-            const float lk = s_l[j + 1];
-            const float u = s_u[j];
+            const float lk = s_l[b0 + j + 1];
+            const float u = s_u[b0 + j];
             const bool ok = swap_accept_test(u, swap_log_prob(a.beta[j], a.beta[j + 1], car_l, lk));
-            s_landed[j] = ok ? j + 1 : car_i;
+            s_landed[b0 + j] = ok ? b0 + j + 1 : car_i;
             car_l = ok ? car_l : lk;
-            car_i = ok ? car_i : j + 1;
+            car_i = ok ? car_i : b0 + j + 1;
           }
-          s_landed[T - 1] = car_i;
+          s_landed[b0 + T - 1] = car_i;
         }
         __syncthreads();
         src = s_landed[base + t];

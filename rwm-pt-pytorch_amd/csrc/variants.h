@@ -127,8 +127,29 @@ constexpr int kNumQuadWidths = (int)(sizeof(kQuadWidths) / sizeof(kQuadWidths[0]
 PTRWM_QUAD_WIDTHS(PTRWM_X_QOK)
 #undef PTRWM_X_QOK
 
-// threads of the workgroup a ladder of n_temps temperatures needs in the lane-split form (narrow ladders: 256)
-inline int quad_block_threads(int n_temps) { return 4 * n_temps > 64 ? ((4 * n_temps + 63) & ~63) : kBlockThreads; }
+// Exchange groups of the lane-split form.  4 T <= 64: one wavefront holds 16 / T whole ladders, four such groups per
+// 256-thread workgroup.  Longer ladders: the group is the workgroup; it holds as many whole ladders as make the best use
+// of its lanes within 256 threads (T = 17: three ladders in 204 of 256 lanes instead of one in 68 of 128), one ladder
+// in 4 T threads rounded up to whole waves when even one does not fit.
+inline int quad_ladders_per_group(int n_temps) {
+  const int need = 4 * n_temps;
+  if (need <= 64) return 64 / need;
+  int best_k = 1;
+  double best_use = 0.0;
+  for (int k = 1; k * need <= kBlockThreads; ++k) {
+    const int b = (k * need + 63) & ~63;
+    const double use = (double)(k * need) / b;
+    if (use > best_use + 1e-9) {
+      best_use = use;
+      best_k = k;
+    }
+  }
+  return best_k;
+}
+inline int quad_block_threads(int n_temps) {
+  const int need = 4 * n_temps;
+  return need <= 64 ? kBlockThreads : ((quad_ladders_per_group(n_temps) * need + 63) & ~63);
+}
 
 // the kernel with this dim compiled in if there is one, else the generic kernel of the dim's class, in the smallest
 // workgroup class that holds the ladder; -1 if none
