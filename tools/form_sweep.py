@@ -33,17 +33,22 @@ def rate(dim, T, C, form, target_steps=2e9):
     return C * T * inner * 3 / (e0.elapsed_time(e1) * 1e-3)
 
 
-cases = [(30, 1, c) for c in (1024, 8192, 32768, 65536, 81920, 98304, 131072, 262144)] + \
-        [(30, 8, c) for c in (1, 64, 1024, 4096, 8192, 16384, 32768)] + \
-        [(30, 32, c) for c in (1, 64, 1024, 2048, 3072, 4096, 8192)] + \
-        [(30, 64, c) for c in (256, 1024, 2048, 4096)] + [(30, 128, c) for c in (128, 1024, 4096)] + \
-        [(50, 1, 65536), (50, 8, 8192), (50, 32, 1024), (50, 32, 4096), (50, 64, 2048)] + \
-        [(100, 1, 65536), (100, 1, 262144), (100, 8, 8192), (100, 8, 65536), (100, 32, 1024), (100, 32, 65536), (100, 64, 1024),
-         (100, 64, 16384), (100, 128, 8192), (80, 32, 16384), (65, 32, 16384), (64, 32, 16384)]
-print(f"{'dim':>4} {'T':>4} {'chains':>7} {'thread-waves/SIMD':>18} {'thread':>10} {'quad':>10} {'quad/thread':>11}")
-for dim, T, C in cases:
-    if not E.has_quad_variant(0, 0, dim, T):
-        continue
-    a, b = rate(dim, T, C, E.FORM_THREAD), rate(dim, T, C, E.FORM_QUAD)
-    w1 = (C * ((T + 63) // 64) if T > 64 else -(-C // (64 // T))) / 1024
-    print(f"{dim:4d} {T:4d} {C:7d} {w1:18.2f} {a:10.3e} {b:10.3e} {b / a:11.2f}", flush=True)
+def main():
+    cases = [(30, 1, c) for c in (1024, 8192, 32768, 65536, 81920, 98304, 131072, 262144)] + \
+            [(30, 8, c) for c in (1, 64, 1024, 4096, 8192, 16384, 32768)] + \
+            [(30, 32, c) for c in (1, 64, 1024, 2048, 3072, 4096, 8192)] + \
+            [(30, 64, c) for c in (256, 1024, 2048, 4096)] + [(30, 128, c) for c in (128, 1024, 4096)] + \
+            [(50, 1, 65536), (50, 8, 8192), (50, 32, 1024), (50, 32, 4096), (50, 64, 2048)] + \
+            [(100, 1, 65536), (100, 1, 262144), (100, 8, 8192), (100, 8, 65536), (100, 32, 1024), (100, 32, 65536), (100, 64, 1024),
+             (100, 64, 16384), (100, 128, 8192), (80, 32, 16384), (65, 32, 16384), (64, 32, 16384)]
+    print(f"{'dim':>4} {'T':>4} {'chains':>7} {'thread-waves/SIMD':>18} {'thread':>10} {'quad':>10} {'quad/thread':>11}")
+    for dim, T, C in cases:
+        if not E.has_quad_variant(0, 0, dim, T):
+            continue
+        a, b = rate(dim, T, C, E.FORM_THREAD), rate(dim, T, C, E.FORM_QUAD)
+        w1 = (C * ((T + 63) // 64) if T > 64 else -(-C // (64 // T))) / 1024
+        print(f"{dim:4d} {T:4d} {C:7d} {w1:18.2f} {a:10.3e} {b:10.3e} {b / a:11.2f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
