@@ -279,9 +279,10 @@ def _prove_mh_flip(r, l_x, l_y, beta_t, u, slack, where):
     return gap / max(thr * tol_r + 6e-8, 1e-300)
 
 
-def _prove_swap_flip(lm, beta, us, swap_mode, swap_order, ev_number, slack, where):
+def _prove_swap_flip(lm, beta, us, swap_mode, swap_order, ev_number, slack, where, in_band=None):
     """Replays one swap event along the oracle's path in fp64 and asserts that at least one attempted pair has its
-    uniform inside the tolerance band of its threshold (so a different outcome is an fp32-level flip)."""
+    uniform inside the tolerance band of its threshold (so a different outcome is an fp32-level flip).
+    in_band: a set - the pairs whose uniform is inside the band are added to it and nothing is asserted."""
     T = len(lm)
     lm = np.array(lm, dtype=np.float64)
     b = np.asarray(beta, dtype=np.float64)
@@ -297,14 +298,18 @@ def _prove_swap_flip(lm, beta, us, swap_mode, swap_order, ev_number, slack, wher
         if np.isfinite(lpr) and np.isfinite(mag):
             tol = (abs(b[j] - b[k]) * float(logp_tol(lm[j]) + logp_tol(lm[k])) + 2.0 ** -22 * mag) * slack
             if lpr < 0 or lpr <= tol:
-                best = min(best, abs(float(us[j]) - thr) / (thr * tol + 6e-8))
+                bands = abs(float(us[j]) - thr) / (thr * tol + 6e-8)
+                best = min(best, bands)
+                if in_band is not None and bands <= 1.0:
+                    in_band.add(j)
         if accepted:
             if swap_mode == O.SWAP_EXCHANGE:
                 lm[j], lm[k] = lm[k], lm[j]
             else:
                 lm[j] = lm[k]
-    assert best <= 1.0, f"{where}: WRONG swap outcome: no attempted pair has its uniform within the fp32 band of its " \
-                        f"threshold (closest is {best:.3g} bands away)"
+    if in_band is None:
+        assert best <= 1.0, f"{where}: WRONG swap outcome: no attempted pair has its uniform within the fp32 band of " \
+                            f"its threshold (closest is {best:.3g} bands away)"
     return best
 
 
@@ -336,8 +341,31 @@ def check_parity(run_a, run_b, spec, prop, *, state, logp, beta, n_steps, burn_i
         bad = np.nonzero(fl | ~same)[0]
         if bad.size == 0:
             # the whole segment agrees: integer bookkeeping must be identical, the jump sums equal to fp32 rounding
-            for k in ("n_accept", "swap_accept", "last_swap_ordinal"):
-                assert np.array_equal(got[k][c], want[k][c]), f"{k} of ladder {c} differs although every decision agrees"
+            assert np.array_equal(got["n_accept"][c], want["n_accept"][c]), \
+                f"n_accept of ladder {c} differs although every decision agrees"
+            diff = np.nonzero((got["swap_accept"][c] != want["swap_accept"][c]) |
+                              (got["last_swap_ordinal"][c] != want["last_swap_ordinal"][c]))[0]
+            if diff.size:
+                # A swap decision can flip WITHOUT a visible trace: the reference's row copy (and any swap between two
+                # replicas that hold the same state, e.g. before either has moved) exchanges identical rows, so only the
+                # counters show it.  Legitimate only if, in some swap event of this segment, the uniform of exactly that
+                # pair sits inside the fp32 band of its threshold (evaluated on the oracle's states): prove it.
+                in_band = set()
+                for d in range(n_steps):
+                    sc = step0 + d + 1
+                    if not (T > 1 and sc > burn_in and sc % swap_every == 0):
+                        continue
+                    pre_x = want["trace"][d - 1, c] if d > 0 else state[c]
+                    _, l_x, l_y, _ = step_log_ratios(spec, prop, pre_x, ext_prop[d, c], beta)
+                    lm = np.where(want["accept_flags"][d, c].astype(bool), l_y, l_x)
+                    ev_rel = events_upto(sc, swap_every, burn_in) - 1 - ev0
+                    _prove_swap_flip(lm, beta, ext_swap_u[ev_rel, c], swap_mode, swap_order, ev0 + ev_rel, slack, "",
+                                     in_band=in_band)
+                assert set(diff.tolist()) <= in_band, \
+                    f"swap bookkeeping of ladder {c} differs at pairs {diff.tolist()} although every decision agrees and " \
+                    f"no swap event has those pairs' uniforms inside the fp32 band of their thresholds (in band: {sorted(in_band)})"
+                assert np.abs(got["swap_accept"][c] - want["swap_accept"][c]).max() <= 2
+                flips.append((step0, c, "swap-invisible", 0.0))
             np.testing.assert_allclose(got["sq_jump"][c], want["sq_jump"][c], rtol=1e-4, atol=1e-9)
             continue
         d = int(bad[0])

@@ -137,3 +137,51 @@ def test_stat_mismatch_without_decision_difference_fails():
 
     with pytest.raises(AssertionError, match="n_accept"):
         H.check_parity(run_a, run, spec, prop, **kw)
+
+
+def test_an_invisible_swap_flip_must_be_provable():
+    """A swap between replicas holding the same state (the reference's row copy produces such pairs) changes only the
+    counters.  The comparator accepts a counter difference on pair j only if some swap event of the segment has pair
+    j's uniform inside the fp32 band of its threshold; otherwise it is a bookkeeping error."""
+    spec, prop, kw = _case(seed=5)
+    kw.update(swap_mode=O.SWAP_REFERENCE_COPY)
+    run = H.oracle_runner(spec, prop)
+    c0, j0 = 2, 1
+
+    def run_a(**k):
+        out = run(**k)
+        if k["state"].shape[0] == kw["state"].shape[0]:
+            out["swap_accept"] = out["swap_accept"].copy()
+            out["swap_accept"][c0, j0] += 1
+        return out
+
+    with pytest.raises(AssertionError, match="swap bookkeeping"):
+        H.check_parity(run_a, run, spec, prop, **kw)
+    # now put pair j0's uniform of one event of ladder c0 on its threshold: the same difference becomes provable
+    base = run(step0=0, **{k: v for k, v in kw.items() if k != "exact_states"})
+    ev, d = 3, None
+    steps = [s for s in range(kw["n_steps"]) if (s + 1) > kw["burn_in"] and (s + 1) % kw["swap_every"] == 0]
+    d = steps[ev]
+    pre = base["trace"][d - 1, c0]
+    _, l_x, l_y, _ = H.step_log_ratios(spec, prop, pre, kw["ext_prop"][d, c0], kw["beta"])
+    lm = np.where(base["accept_flags"][d, c0].astype(bool), l_y, l_x)
+    # reference_copy, sequential: pair j compares the rows as the sweep left them; pair j0 = 1 sees row 1 (untouched so far)
+    lm_seq = lm.copy()
+    for j in range(j0):  # replay the earlier pairs to know what sits at j0
+        lpr = (kw["beta"][j] - kw["beta"][j + 1]) * (lm_seq[j + 1] - lm_seq[j])
+        if kw["ext_swap_u"][ev, c0, j] < min(1.0, np.exp(lpr)):
+            lm_seq[j] = lm_seq[j + 1]
+    lpr = float((kw["beta"][j0] - kw["beta"][j0 + 1]) * (lm_seq[j0 + 1] - lm_seq[j0]))
+    thr = min(1.0, float(np.exp(lpr)))
+    kw["ext_swap_u"][ev, c0, j0] = f32(min(thr * (1 - 2e-6), 1 - 2e-7)) if thr > 0.01 else f32(thr)
+    out2 = run(step0=0, **{k: v for k, v in kw.items() if k != "exact_states"})
+
+    def run_b(**k):  # engine A: the oracle's outputs with ONE extra count on that pair (as an invisible flip would leave)
+        out = run(**k)
+        if k["state"].shape[0] == kw["state"].shape[0]:
+            out["swap_accept"] = out["swap_accept"].copy()
+            out["swap_accept"][c0, j0] += 1
+        return out
+
+    flips = H.check_parity(run_b, run, spec, prop, **kw)
+    assert ("swap-invisible" in [f[2] for f in flips]) and out2["swap_accept"].shape == base["swap_accept"].shape
