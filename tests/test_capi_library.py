@@ -178,3 +178,23 @@ def test_product_refuses_to_run_without_its_library_or_a_gpu(engine, tmp_path):
             if f.endswith((".py", ".h", ".hip")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f
+
+
+def test_build_gate_holds_for_the_built_objects():
+    """tools/kernel_stats.py --check on the objects the library was linked from: no kernel in the register regime hipcc
+    miscompiled twice (> 256 VGPRs / any AGPR), no scratch in production step kernels of the max-ILP group.  (The
+    Makefile runs the same gate; this keeps it visible in the test report.)"""
+    import glob
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    objdir = os.path.join(root, "rwm-pt-pytorch_amd", "build")
+    if not glob.glob(os.path.join(objdir, "*.o")):
+        pytest.skip("no object files (library built elsewhere)")
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("ROCm LLVM tools not installed")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_stats.py"), "--check", "--objdir", objdir],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
+    assert "every kernel <= 256 VGPRs and no AGPRs" in r.stdout
