@@ -26,15 +26,19 @@ def build(device, n_ladders, offset):
 
 def main():
     rank, world, port, C, steps, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+    backend = sys.argv[7] if len(sys.argv) > 7 else "gloo"  # "nccl" = RCCL (one rank per GPU; here: world size 1)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     from algorithms.sharding import allreduce_summary
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")  # NO torch.cuda.set_device: the binding's device guard must do it
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     alg = build(dev, C, rank * C)
     alg._advance(steps)
     torch.cuda.synchronize()
-    total = allreduce_summary(alg._run.summary(), torch.device("cpu"))
+    total = allreduce_summary(alg._run.summary(), dev if backend == "nccl" else torch.device("cpu"))
     np.savez(out, state=alg._run.state.cpu().numpy(), logp=alg._run.logp.cpu().numpy(),
              n_accept=alg._run.n_accept.cpu().numpy(),
              **{f"sum_{k}": (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in total.items()})

@@ -568,6 +568,40 @@ def test_two_gpu_processes_equal_one(device, tmp_path):
         assert float(p["sum_swap_acceptance_rate"]) == want["swap_acceptance_rate"]
 
 
+def test_summary_allreduce_over_rccl(device, tmp_path):
+    """The collective bench.py uses at N > 1 - one all_reduce(SUM) of the packed summary over RCCL (backend "nccl") on
+    device tensors - exercised on this box with a world of one fresh process: the communicator comes up, the reduced
+    summary equals the local one."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from algorithms.sharding import allreduce_summary
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mp_gpu_worker as W
+
+    C, steps = 500, 40
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mp_gpu_worker.py")
+    out = str(tmp_path / "rccl.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, worker, "0", "1", str(port), str(C), str(steps), out, "nccl"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    p = np.load(out)
+    one = W.build(device, C, 0)
+    one._advance(steps)
+    want = allreduce_summary(one._run.summary(), torch.device("cpu"))
+    assert np.array_equal(p["state"], one._run.state.cpu().numpy())
+    assert int(p["sum_n_replicas"]) == C and int(p["sum_swap_attempts"]) == want["swap_attempts"]
+    assert np.array_equal(p["sum_accept_count"], want["accept_count"].numpy())
+    np.testing.assert_allclose(p["sum_esjd"], want["esjd"].numpy(), rtol=1e-12)
+
+
 def test_sampler_on_a_second_gpu_without_set_device():
     """a sampler constructed with device='cuda:1' while cuda:0 is the process's current device must launch
     on cuda:1 (the binding's on_device guard; the library itself never switches devices) and give the bits it gives on
