@@ -27,7 +27,8 @@ struct VariantPair {
 //                    issues one VALU instruction per ~5 cycles instead of ~3.4, and below one wave per SIMD the split
 //                    puts four times as many SIMDs to work (2.5-3.2x for a single ladder)
 //   32 < dim <= 64   the four lanes own 16 dims each, so dims well below 64 waste lanes (dim 50: 28 %): lane-split when
-//                    w < 0.75, or always for dim >= 60 (there the thread kernel is held to two waves per SIMD)
+//                    w < 0.75, or w < 2 for dim >= 57 (two waves of the 64-wide thread kernel per SIMD: quad is 9-25 %
+//                    faster below that); at full batches the thread kernel is 4-30 % faster at every dim of the class
 //   dim > 64         lane-split always: it is the only form there (the one-thread-per-replica kernel needed 340-420
 //                    VGPRs - one wave per SIMD, 8-25 % slower at full batches, 1.8x at small ones - and sat in the
 //                    register regime in which hipcc miscompiled it twice; see variants.h)
@@ -457,7 +458,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
       else if (target->dim <= 32)
         faster = args->n_temps <= 16 ? w < 1.6 : w < 1.0;
       else
-        faster = w < 0.75 || (target->dim >= 60 && args->n_temps <= 64);
+        faster = w < (target->dim >= 57 ? 2.0 : 0.75);
       quad = fn == nullptr || form == PTRWM_FORM_QUAD || faster;
       if (quad) fn = qfn;
     }

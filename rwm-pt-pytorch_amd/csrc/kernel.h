@@ -369,15 +369,12 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       for (int d = 0; d < DP; ++d)
         if (d < D) x[d] = acc ? y[d] : x[d];
 #else
-#pragma unroll
-      for (int d = 0; d < DP; ++d) {
-        if (d < D) {
-          const float dl = sub_rn(y[d], x[d]);
-          j2p[d / W] = fmaf(dl, dl, j2p[d / W]);
-          x[d] = acc ? y[d] : x[d];
-        }
+      PTRWM_DIM_LOOP(d, DP, D, {
+        const float dl = sub_rn(y[d], x[d]);
+        j2p[d / W] = fmaf(dl, dl, j2p[d / W]);
+        x[d] = acc ? y[d] : x[d];
         if ((d & PTRWM_J2_FENCE_MASK) == PTRWM_J2_FENCE_MASK) sched_fence_soft();
-      }
+      })
 #endif
       j2 = tree4_add(j2p);
       if (!acc) j2 = 0.0f;
@@ -421,22 +418,17 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       // fetches the row of slot `src` (rows exchanged through LDS: 2 LDS ops per dimension, no HBM)
       {
         float *my_row = rows + slot * D;
-#pragma unroll
-        for (int d = 0; d < DP; ++d)
-          if (d < D) my_row[d] = acc ? y[d] : x[d];
+        PTRWM_DIM_LOOP(d, DP, D, { my_row[d] = acc ? y[d] : x[d]; })
         sync_group();
         const int Dr = fresh_dim<EXACT>(D0);  // generic widths: fresh d < dim compares instead of 2*DP live masks
         const float *src_row = rows + src * Dr;
-#pragma unroll
-        for (int d = 0; d < DP; ++d) {
-          if (d < Dr) {
-            const float w = src_row[d];
-            const float dl = sub_rn(w, x[d]);
-            j2p[d / W] = fmaf(dl, dl, j2p[d / W]);
-            x[d] = w;
-          }
+        PTRWM_DIM_LOOP(d, DP, Dr, {
+          const float w = src_row[d];
+          const float dl = sub_rn(w, x[d]);
+          j2p[d / W] = fmaf(dl, dl, j2p[d / W]);
+          x[d] = w;
           if ((d & 7) == 7) sched_fence_soft();
-        }
+        })
         j2 = tree4_add(j2p);
       }
       lp = my_l;
@@ -457,9 +449,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       if (trace_now && trace_on) {
         const long long row = ((a.full.trace_row0 + trace_rows) * a.full.trace_chains + chain) * a.full.trace_temps + t;
         float *__restrict__ tr = a.full.trace + row * D;
-#pragma unroll
-        for (int d = 0; d < DP; ++d)
-          if (d < D) tr[d] = x[d];
+        PTRWM_DIM_LOOP(d, DP, D, { tr[d] = x[d]; })
         if (a.full.trace_logp != nullptr) a.full.trace_logp[row] = lp;
       }
       trace_rows += trace_now ? 1 : 0;

@@ -150,6 +150,24 @@ __device__ __forceinline__ float div_rn(float a, float b) {
   return a / b;
 }
 
+// ---- loops over the dimensions of a replica -----------------------------------------------------------------------
+// PTRWM_DIM_LOOP(d, DP, D, body): `body` for every d < D, with d a compile-time constant after unrolling (static register
+// indices).  When D is a compile-time constant (kernels with dim compiled in) everything folds to the plain unrolled
+// loop.  When D is a run-time, wave-uniform value the dimensions are walked in blocks of four: a block entirely below D
+// runs without per-dimension tests, only the one block that straddles D tests each dimension, blocks above are skipped
+// - one scalar compare-and-branch per four dimensions instead of one per dimension (the generic-width kernels spent
+// ~110 scalar branches per step on those).  The body is instantiated twice per block in that case.
+#define PTRWM_DIM_LOOP(d, DP, D, ...)                                                          \
+  _Pragma("unroll") for (int d##_blk = 0; d##_blk < (DP); d##_blk += 4) {                      \
+    if (d##_blk + 4 <= (D)) {                                                                  \
+      _Pragma("unroll") for (int d = d##_blk; d < d##_blk + 4; ++d)                            \
+        if (d < (DP)) { __VA_ARGS__ }                                                          \
+    } else if (d##_blk < (D)) {                                                                \
+      _Pragma("unroll") for (int d = d##_blk; d < d##_blk + 4; ++d)                            \
+        if (d < (DP) && d < (D)) { __VA_ARGS__ }                                               \
+    }                                                                                          \
+  }
+
 // ---- canonical reduction order -------------------------------------------------------------------------------
 // Every sum over the dimensions of a replica (log-density terms, squared jump, the UniformRadius norm) is taken in ONE
 // order, whatever kernel evaluates it: the dimensions are cut into FOUR contiguous ranges of canon_width() entries,

@@ -38,7 +38,19 @@ __device__ __forceinline__ void philox_normals(float (&z)[DP], int D, const RngC
   constexpr int NB = (2 * ((DP + 1) / 2)) / 4 + 1;  // blocks up to the one holding word 2*ceil(DP/2)
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
-    if (4 * c <= w_a + 1) {
+    if (4 * c + 4 <= DP && 4 * c + 4 <= D) {
+      // a block entirely below dim: no per-pair tests (see PTRWM_DIM_LOOP); w_a >= D lies in a later block
+      const u32x4 r = philox4x32_10(rc.c0hi | (uint32_t)c, rc.c1, rc.c2, rc.c3, rc.k0, rc.k1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int d = (4 * c + 2 * h + 1 < DP) ? 4 * c + 2 * h : 0;
+        float z0, z1;
+        box_muller(h ? r.z : r.x, h ? r.w : r.y, z0, z1);
+        z[d] = z0;
+        z[d + 1] = z1;
+      }
+      sched_fence();
+    } else if (4 * c <= w_a + 1) {
       const u32x4 r = philox4x32_10(rc.c0hi | (uint32_t)c, rc.c1, rc.c2, rc.c3, rc.k0, rc.k1);
       if (4 * c < DP && 4 * c < D) {
         float z0, z1;
@@ -78,7 +90,20 @@ __device__ __forceinline__ float philox_normal_step(float (&y)[DP], const float 
   float u_acc = 0.0f;
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
-    if (4 * c <= w_a) {
+    if (4 * c + 4 <= DP && 4 * c + 4 <= D) {
+      // a block entirely below dim: no per-pair tests (run-time dim: one scalar branch per block, see PTRWM_DIM_LOOP)
+      const u32x4 r = philox4x32_10(rc.c0hi | (uint32_t)c, rc.c1, rc.c2, rc.c3, rc.k0, rc.k1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int d = (4 * c + 2 * h + 1 < DP) ? 4 * c + 2 * h : 0;
+        const uint32_t ra = h ? r.z : r.x, rb = h ? r.w : r.y;
+        const float rad = tscale * hw_sqrt(bm_radius_sq(ra));
+        const float ang = bm_turns(rb);
+        y[d] = fmaf(rad, __builtin_amdgcn_sinf(ang), x[d]);
+        y[d + 1] = fmaf(rad, __builtin_amdgcn_cosf(ang), x[d + 1]);
+      }
+      sched_fence();
+    } else if (4 * c <= w_a) {
       const u32x4 r = philox4x32_10(rc.c0hi | (uint32_t)c, rc.c1, rc.c2, rc.c3, rc.k0, rc.k1);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -150,7 +175,16 @@ struct LaplaceProposal {
       constexpr int NB = DP / 4 + 1;
 #pragma unroll
       for (int c = 0; c < NB; ++c) {
-        if (4 * c <= D) {
+        if (4 * c + 4 <= DP && 4 * c + 4 <= D) {
+          // a block entirely below dim: no per-dimension tests (see PTRWM_DIM_LOOP)
+          const u32x4 r = philox4x32_10(rc.c0hi | (uint32_t)c, rc.c1, rc.c2, rc.c3, rc.k0, rc.k1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int d = (4 * c + q < DP) ? 4 * c + q : 0;
+            y[d] = add_rn(x[d], transform(u01(pick(r, q)), mul_rn(dsc[d], tscale)));
+          }
+          sched_fence();
+        } else if (4 * c <= D) {
           const u32x4 r = philox4x32_10(rc.c0hi | (uint32_t)c, rc.c1, rc.c2, rc.c3, rc.k0, rc.k1);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -191,15 +225,15 @@ struct UniformRadiusProposal {
     }
     constexpr int W = canon_width(DP);
     float n2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // |g|^2 in the canonical four-range order (philox.h)
-#pragma unroll
-    for (int d = 0; d < DP; ++d)
-      if (d < D) n2p[d / W] = fmaf(y[d], y[d], n2p[d / W]);
+    PTRWM_DIM_LOOP(d, DP, D, { n2p[d / W] = fmaf(y[d], y[d], n2p[d / W]); })
     const float nrm = hw_sqrt(tree4_add(n2p));
     const float safe = nrm > 1e-12f ? nrm : 1.0f;
     const float rad = tscale * hw_exp2(pp.inv_dim * hw_log2(u_rad));
     // g / n as g * (1/n) with one IEEE reciprocal per step: <= 1.5 ulp from the reference's per-element division
     // (uniform.py:58), and ~10 VALU instructions per dimension cheaper
     const float inv = div_rn(1.0f, safe);
+    // per-dimension tests here, not PTRWM_DIM_LOOP: with the two instances of this in-place update per block the
+    // optimiser merges them into one with a selected INDEX, which moves y[] to scratch (tools/kernel_stats.py --check)
 #pragma unroll
     for (int d = 0; d < DP; ++d)
       if (d < D) y[d] = add_rn(x[d], mul_rn(mul_rn(y[d], inv), rad));

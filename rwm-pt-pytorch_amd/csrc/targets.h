@@ -78,29 +78,26 @@ struct RoughCarpetT {
     const float nh = -0.5f * kLog2e;
     constexpr int W = canon_width(DP);
     float sm[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pr[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // canonical four-range partials (philox.h)
-#pragma unroll
-    for (int d = 0; d < DP; ++d) {
-      if (d < D) {
-        float d0, d1, d2;
-        if constexpr (SCALED) {
-          // s x - m_k as ONE explicit fma each (what the optimiser chose when left alone, now the same in every kernel)
-          const float sc = uv0[d];
-          d0 = fmaf(y[d], sc, -m0), d1 = fmaf(y[d], sc, -m1), d2 = fmaf(y[d], sc, -m2);
-        } else {
-          d0 = y[d] - m0, d1 = y[d] - m1, d2 = y[d] - m2;
-        }
-        float mx, s;
-        rc_dim_term<STRICT, TWO>(d0, d1, d2, nh, w0, w1, w2, mx, s);
-#ifdef PTRWM_RC_PROD_FIRST
-        pr[d / W] = mul_rn(pr[d / W], s);
-        sm[d / W] = add_rn(sm[d / W], mx);
-#else
-        sm[d / W] = add_rn(sm[d / W], mx);
-        pr[d / W] = mul_rn(pr[d / W], s);
-#endif
+    PTRWM_DIM_LOOP(d, DP, D, {
+      float d0, d1, d2;
+      if constexpr (SCALED) {
+        // s x - m_k as ONE explicit fma each (what the optimiser chose when left alone, now the same in every kernel)
+        const float sc = uv0[d];
+        d0 = fmaf(y[d], sc, -m0), d1 = fmaf(y[d], sc, -m1), d2 = fmaf(y[d], sc, -m2);
+      } else {
+        d0 = y[d] - m0, d1 = y[d] - m1, d2 = y[d] - m2;
       }
+      float mx, s;
+      rc_dim_term<STRICT, TWO>(d0, d1, d2, nh, w0, w1, w2, mx, s);
+#ifdef PTRWM_RC_PROD_FIRST
+      pr[d / W] = mul_rn(pr[d / W], s);
+      sm[d / W] = add_rn(sm[d / W], mx);
+#else
+      sm[d / W] = add_rn(sm[d / W], mx);
+      pr[d / W] = mul_rn(pr[d / W], s);
+#endif
       if ((d & PTRWM_RC_FENCE_MASK) == PTRWM_RC_FENCE_MASK) sched_fence_soft();
-    }
+    })
     const float sum_mx = tree4_add(sm);
     // each factor is in [1, 3] and a range holds at most 28 of them: the product of two ranges (<= 3^56) cannot
     // overflow, the product of all four could (3^112), so the log is taken per pair of ranges
@@ -132,22 +129,19 @@ struct ThreeMixture {
     float q0p[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q1p[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const const_float_ptr uv0 = uniform_vec(tp.vec0);
     [[maybe_unused]] const const_float_ptr uv1 = SCALED ? uniform_vec(tp.vec1) : nullptr;
-#pragma unroll
-    for (int d = 0; d < DP; ++d) {
-      if (d < D) {
-        float e0, e1, e2;
-        if constexpr (SCALED) {
-          const float sc = uv1[d];  // s x - mu_k as one explicit fma each, the same in every kernel
-          e0 = fmaf(y[d], sc, -uv0[d]), e1 = fmaf(y[d], sc, -uv0[D + d]), e2 = fmaf(y[d], sc, -uv0[2 * D + d]);
-        } else {
-          e0 = sub_rn(y[d], uv0[d]), e1 = sub_rn(y[d], uv0[D + d]), e2 = sub_rn(y[d], uv0[2 * D + d]);
-        }
-        q0p[d / W] = fmaf(e0, e0, q0p[d / W]);
-        q1p[d / W] = fmaf(e1, e1, q1p[d / W]);
-        q2p[d / W] = fmaf(e2, e2, q2p[d / W]);
+    PTRWM_DIM_LOOP(d, DP, D, {
+      float e0, e1, e2;
+      if constexpr (SCALED) {
+        const float sc = uv1[d];  // s x - mu_k as one explicit fma each, the same in every kernel
+        e0 = fmaf(y[d], sc, -uv0[d]), e1 = fmaf(y[d], sc, -uv0[D + d]), e2 = fmaf(y[d], sc, -uv0[2 * D + d]);
+      } else {
+        e0 = sub_rn(y[d], uv0[d]), e1 = sub_rn(y[d], uv0[D + d]), e2 = sub_rn(y[d], uv0[2 * D + d]);
       }
+      q0p[d / W] = fmaf(e0, e0, q0p[d / W]);
+      q1p[d / W] = fmaf(e1, e1, q1p[d / W]);
+      q2p[d / W] = fmaf(e2, e2, q2p[d / W]);
       if ((d & 7) == 7) sched_fence_soft();
-    }
+    })
     const float q0 = tree4_add(q0p), q1 = tree4_add(q1p), q2 = tree4_add(q2p);
     return finish(q0, q1, q2, tp);
   }
@@ -180,16 +174,13 @@ struct FullRosenbrock {
     constexpr int W = canon_width(DP);
     float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // term i belongs to the range of dim i
     const const_float_ptr uv0 = uniform_vec(tp.vec0);
-#pragma unroll
-    for (int i = 0; i + 1 < DP; ++i) {
-      if (i + 1 < D) {
-        const float r = y[i + 1] - y[i] * y[i];
-        const float c = y[i] - uv0[i];
-        s1[i / W] = fmaf(b * r, r, s1[i / W]);
-        s2[i / W] = fmaf(a * c, c, s2[i / W]);
-      }
+    PTRWM_DIM_LOOP(i, DP - 1, D - 1, {  // terms i = 0 .. D-2
+      const float r = y[i + 1] - y[i] * y[i];
+      const float c = y[i] - uv0[i];
+      s1[i / W] = fmaf(b * r, r, s1[i / W]);
+      s2[i / W] = fmaf(a * c, c, s2[i / W]);
       if ((i & 7) == 7) sched_fence_soft();
-    }
+    })
     return -(tree4_add(s1) + tree4_add(s2));
   }
 };
@@ -206,16 +197,13 @@ struct EvenRosenbrock {
     constexpr int W = canon_width(DP);  // even: a pair (2i, 2i+1) never straddles two ranges
     float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const const_float_ptr uv0 = uniform_vec(tp.vec0);
-#pragma unroll
-    for (int i = 0; 2 * i + 1 < DP; ++i) {
-      if (2 * i + 1 < D) {
-        const float c = y[2 * i] - uv0[i];
-        const float r = y[2 * i + 1] - y[2 * i] * y[2 * i];
-        s1[(2 * i) / W] = fmaf(a * c, c, s1[(2 * i) / W]);
-        s2[(2 * i) / W] = fmaf(b * r, r, s2[(2 * i) / W]);
-      }
+    PTRWM_DIM_LOOP(i, DP / 2, D >> 1, {  // pairs i = 0 .. D/2 - 1
+      const float c = y[2 * i] - uv0[i];
+      const float r = y[2 * i + 1] - y[2 * i] * y[2 * i];
+      s1[(2 * i) / W] = fmaf(a * c, c, s1[(2 * i) / W]);
+      s2[(2 * i) / W] = fmaf(b * r, r, s2[(2 * i) / W]);
       if ((i & 3) == 3) sched_fence_soft();
-    }
+    })
     return -(tree4_add(s1) + tree4_add(s2));
   }
 };
@@ -234,9 +222,8 @@ struct HybridRosenbrock {
     const float c0 = y[0] - mu;
     constexpr int W = canon_width(DP);
     float acc[4] = {a * c0 * c0, 0.0f, 0.0f, 0.0f};  // the x_0 term opens the chain of the first range
-#pragma unroll
-    for (int i = 1; i < DP; ++i) {
-      if (i < D) {
+    PTRWM_DIM_LOOP(i, DP, D, {
+      if (i >= 1) {
         const bool head = (tp.mask[i >> 6] >> (i & 63)) & 1ull;
         // select between the two VALUES: left alone the optimiser selects the INDEX (head ? 0 : i - 1), which makes
         // y[] dynamically indexed and moves the whole vector to scratch memory (16 + 4 DP bytes per thread, found by
@@ -248,7 +235,7 @@ struct HybridRosenbrock {
         acc[i / W] = fmaf(b * r, r, acc[i / W]);
       }
       if ((i & 7) == 7) sched_fence_soft();
-    }
+    })
     return -tree4_add(acc);
   }
 };
@@ -266,15 +253,12 @@ struct IIDGamma {
     constexpr int W = canon_width(DP);
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     bool bad = false;
-#pragma unroll
-    for (int d = 0; d < DP; ++d) {
-      if (d < D) {
-        const float v = y[d];
-        bad = bad || (v <= 0.0f);
-        acc[d / W] += fmaf(km1, hw_log2(v), -(v * inv_theta));
-      }
+    PTRWM_DIM_LOOP(d, DP, D, {
+      const float v = y[d];
+      bad = bad || (v <= 0.0f);
+      acc[d / W] += fmaf(km1, hw_log2(v), -(v * inv_theta));
       if ((d & 7) == 7) sched_fence_soft();
-    }
+    })
     return bad ? kNegInf : tree4_add(acc) - tp.p[2];
   }
 };
@@ -292,15 +276,12 @@ struct IIDBeta {
     constexpr int W = canon_width(DP);
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     bool bad = false;
-#pragma unroll
-    for (int d = 0; d < DP; ++d) {
-      if (d < D) {
-        const float v = y[d];
-        bad = bad || (v <= 0.0f) || (v >= 1.0f);
-        acc[d / W] += fmaf(am1, hw_log2(v), bm1 * hw_log2(1.0f - v));
-      }
+    PTRWM_DIM_LOOP(d, DP, D, {
+      const float v = y[d];
+      bad = bad || (v <= 0.0f) || (v >= 1.0f);
+      acc[d / W] += fmaf(am1, hw_log2(v), bm1 * hw_log2(1.0f - v));
       if ((d & 7) == 7) sched_fence_soft();
-    }
+    })
     return bad ? kNegInf : tree4_add(acc) + tp.p[2];
   }
 };
@@ -317,19 +298,16 @@ struct DiagGaussian {
     float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const const_float_ptr uv0 = uniform_vec(tp.vec0);
     [[maybe_unused]] const const_float_ptr uv1 = SCALED_FORM ? nullptr : uniform_vec(tp.vec1);
-#pragma unroll
-    for (int d = 0; d < DP; ++d) {
-      if (d < D) {
-        if constexpr (SCALED_FORM) {
-          const float sx = uv0[d] * y[d];
-          q[d / W] = fmaf(sx, sx, q[d / W]);
-        } else {
-          const float c = y[d] - uv0[d];
-          q[d / W] = fmaf(c * uv1[d], c, q[d / W]);
-        }
+    PTRWM_DIM_LOOP(d, DP, D, {
+      if constexpr (SCALED_FORM) {
+        const float sx = uv0[d] * y[d];
+        q[d / W] = fmaf(sx, sx, q[d / W]);
+      } else {
+        const float c = y[d] - uv0[d];
+        q[d / W] = fmaf(c * uv1[d], c, q[d / W]);
       }
       if ((d & 7) == 7) sched_fence_soft();
-    }
+    })
     return tree4_add(q);
   }
   template <bool STRICT = false>
@@ -349,9 +327,7 @@ struct Hypercube {
 #pragma clang fp contract(off)
     const float lo = tp.p[0], hi = tp.p[1];
     bool inside = true;
-#pragma unroll
-    for (int d = 0; d < DP; ++d)
-      if (d < D) inside = inside && (y[d] >= lo) && (y[d] <= hi);
+    PTRWM_DIM_LOOP(d, DP, D, { inside = inside && (y[d] >= lo) && (y[d] <= hi); })
     return inside ? tp.p[2] : kNegInf;
   }
 };
@@ -371,14 +347,13 @@ struct NealFunnel {
     const float prior = -0.5f * log_2pi - 0.5f * (hw_log2(s2) * kLn2) - 0.5f * (dv * dv) / s2;
     constexpr int W = canon_width(DP);
     float ssp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int d = 1; d < DP; ++d) {
-      if (d < D) {
+    PTRWM_DIM_LOOP(d, DP, D, {
+      if (d >= 1) {
         const float c = y[d] - mu_z;
         ssp[d / W] = fmaf(c, c, ssp[d / W]);
       }
       if ((d & 7) == 7) sched_fence_soft();
-    }
+    })
     const float ss = tree4_add(ssp);
     const float dm1 = (float)(D - 1);
     const float lik = -0.5f * dm1 * log_2pi - 0.5f * dm1 * v - 0.5f * hw_exp(-v) * ss;

@@ -40,7 +40,9 @@ def main():
             [(30, 64, c) for c in (256, 1024, 2048, 4096)] + [(30, 128, c) for c in (128, 1024, 4096)] + \
             [(50, 1, 65536), (50, 8, 8192), (50, 32, 1024), (50, 32, 4096), (50, 64, 2048)] + \
             [(100, 1, 65536), (100, 1, 262144), (100, 8, 8192), (100, 8, 65536), (100, 32, 1024), (100, 32, 65536), (100, 64, 1024),
-             (100, 64, 16384), (100, 128, 8192), (80, 32, 16384), (65, 32, 16384), (64, 32, 16384)]
+             (100, 64, 16384), (100, 128, 8192), (80, 32, 16384), (65, 32, 16384), (64, 32, 16384)] + \
+            [(d, 32, c) for d in (41, 48, 57, 64) for c in (1024, 1536, 2048, 3072, 4096)] + \
+            [(d, 1, c) for d in (48, 64) for c in (32768, 65536, 98304, 131072)]
     print(f"{'dim':>4} {'T':>4} {'chains':>7} {'thread-waves/SIMD':>18} {'thread':>10} {'quad':>10} {'quad/thread':>11}")
     for dim, T, C in cases:
         if not E.has_quad_variant(0, 0, dim, T):

@@ -18,8 +18,11 @@ name, flt = sys.argv[1], sys.argv[2]
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 tmp = tempfile.mkdtemp(prefix="khist_")
 src = os.path.join(ROOT, "rwm-pt-pytorch_amd", "csrc", f"variants_{name}.hip")
+# the Makefile's flags for the max-ILP group (override with PTRWM_HIST_FLAGS)
+flags = os.environ.get("PTRWM_HIST_FLAGS", "-mllvm -enable-post-misched=0 -mllvm -amdgpu-sched-strategy=max-ilp "
+                                            "-fno-slp-vectorize").split()
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-save-temps=obj", "-c", src,
-                       "-o", os.path.join(tmp, "v.o")], stderr=subprocess.DEVNULL)
+                       "-o", os.path.join(tmp, "v.o")] + flags, stderr=subprocess.DEVNULL, cwd=tmp)
 lines = open(os.path.join(tmp, f"variants_{name}-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith("_ZN5ptrwm17ptrwm_step_kernel") and flt in l and l.rstrip().endswith(
     ("EEvNS_5KArgsE:", "KArgsE")) or (l.startswith("_ZN5ptrwm17ptrwm_step_kernel") and flt in l and ":" in l))
