@@ -198,3 +198,19 @@ def test_build_gate_holds_for_the_built_objects():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
     assert "every kernel <= 256 VGPRs and no AGPRs" in r.stdout
+
+
+def test_a_compiled_caller_links_and_validates_without_python(engine):
+    """tests/capi_host/capi_host_test.cpp: a C++ program against include/ptrwm.h - no Python, no torch in the process.
+    Its --symbols mode needs no GPU (ABI version, variant queries, every validation error code)."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
+
+    exe = __graft_entry__.build_capi_host_test()
+    out = subprocess.run([exe, "--symbols"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "symbols ok" in out.stdout
+    libs = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    names = [ln.split()[0] for ln in libs.splitlines() if ln.strip()]  # sonames (the tree's own path contains "pytorch")
+    assert any(n.startswith("libptrwm_hip.so") for n in names)
+    assert not any("torch" in n or "python" in n.lower() or n.startswith("libc10") for n in names), names

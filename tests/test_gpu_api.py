@@ -987,3 +987,22 @@ def test_superfunnel_runs_through_split_steps(device):
     assert cold.shape == (150, t.dim) and torch.isfinite(cold).all()
     assert torch.isfinite(pt._run.logp).all() and (pt._run.state[..., -2:] > 1e-9).all()
     assert 0.05 < float(pt.mh_acceptance_rates()[0]) < 0.95 and pt.num_swap_attempts > 0
+
+
+def test_a_compiled_caller_runs_the_c_abi_without_python_or_torch(device):
+    """tests/capi_host/capi_host_test.cpp --run: a C++ process (hipMalloc'd buffers, its own stream, no Python, no
+    torch) drives ptrwm_logdensity and ptrwm_run in several launches - PT-RWM RoughCarpet and RWM ThreeMixture /
+    Laplace, both kernel forms - and checks each against oracle_run_f32 on the same Philox stream."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__
+
+    exe = __graft_entry__.build_capi_host_test()
+    out = subprocess.run([exe, "--run"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "capi host test ok" in out.stdout
+    assert out.stdout.count("ladders identical to the oracle") == 4
