@@ -72,11 +72,23 @@ struct QLane {
   int d0;     // first owned dimension, q W
 };
 
+// A lane-dependent value behind an empty asm: compares against it are redone where they are used (one v_cmp each)
+// instead of being hoisted out of the step loop as 64-bit lane masks - in the kernels with a run-time dim that was
+// dozens of SGPR pairs, spilled to VGPR lanes and fetched back with v_readlane (157 SGPR spills at width 28; dims
+// 65..104 other than 100 gained 3-9 %, dims 16..64 in this form 2-3 %).
+__device__ __forceinline__ int q_fresh(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 // valid(j): does local slot j hold a dimension?  MIN_OWN (a compile-time lower bound of n_own over the four lanes, known
-// when dim is compiled in) lets the compiler drop the test for the slots every lane owns.
+// when dim is compiled in) lets the compiler drop the test for the slots every lane owns; -1 = dim at run time.
+// (Tried and measured slower, profiles/r02_bench_variants.txt: one divergent region per block of four slots instead of
+// per slot; computing every slot with selects on the accumulators; building each slot's lane mask on the scalar unit
+// from two wave masks and inverse_ballot - 14 % fewer VALU instructions, but 2-6 % slower.)
 template <int MIN_OWN>
 __device__ __forceinline__ bool q_valid(const QLane &l, int j) {
-  return j < MIN_OWN || j < l.n_own;
+  if constexpr (MIN_OWN >= 0) return j < MIN_OWN || j < l.n_own;  // dim compiled in: a handful of distinct masks
+  return j < q_fresh(l.n_own);
 }
 
 // ---- proposals ---------------------------------------------------------------------------------------------------------
@@ -152,7 +164,9 @@ struct QLaplace {
         for (int k = 0; k < 4; ++k) {
           const int j = 4 * b + k;
           if (q_valid<MIN_OWN>(l, j)) y[j] = add_rn(x[j], LaplaceProposal<W>::transform(u01(pick(r, k)), mul_rn(dsc[j], tscale)));
-          if ((int)(4 * cb) + k == D) u_loc = u01(pick(r, k));
+          // the accept word (word D) sits at position D & 3 of block D >> 2: the position is wave-uniform (a constant
+          // when dim is compiled in), only the block is lane-dependent - one compare per block, not one per word
+          if (k == (D & 3)) u_loc = ((int)cb == c_a) ? u01(pick(r, k)) : u_loc;
         }
         quad_rng_fence();
       }
@@ -549,7 +563,7 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
       __builtin_amdgcn_wave_barrier();
     }
   };
-  constexpr int MIN_OWN = DEXACT ? (DEXACT - 3 * W > 0 ? (DEXACT - 3 * W > W ? W : DEXACT - 3 * W) : 0) : 0;
+  constexpr int MIN_OWN = DEXACT ? (DEXACT - 3 * W > 0 ? (DEXACT - 3 * W > W ? W : DEXACT - 3 * W) : 0) : -1;
 
   // ---- state load: the group's live replicas are one contiguous run of floats: coalesced copy into the slab, then
   // every lane picks its quarter of its replica's row (row stride = dim)

@@ -175,9 +175,10 @@ struct QuadVariants {
   RunLaunchFn run[PTRWM_PROPOSAL_COUNT][kNumQuadWidths];
 };
 
-// MIN_OWN of quad.h: the number of dimensions the LAST lane owns when dim is compiled in (every lane owns at least that)
+// MIN_OWN of quad.h: the number of dimensions the LAST lane owns when dim is compiled in (every lane owns at least
+// that); -1 marks the kernels that take dim at run time
 constexpr int quad_min_own(int w, int dexact) {
-  return dexact == 0 ? 0 : (dexact - 3 * w <= 0 ? 0 : (dexact - 3 * w > w ? w : dexact - 3 * w));
+  return dexact == 0 ? -1 : (dexact - 3 * w <= 0 ? 0 : (dexact - 3 * w > w ? w : dexact - 3 * w));
 }
 
 template <class Target, class Proposal, int W, int DEXACT, int MAXT>
