@@ -798,3 +798,44 @@ def test_randomised_split_steps_against_the_fused_kernel(device):
                        text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
     assert "60 cases: split steps reproduce the fused kernel bit for bit" in r.stdout
+
+
+def test_philox_stream_quality_on_the_run_layout(device):
+    """The in-kernel randoms are this engine's own design (the reference draws torch.randn / torch.rand ahead of its
+    loop, rwm_gpu_optimized.py:490-511), so their quality is checked on the layout ptrwm_run really uses - one Philox
+    subsequence per (chain, temperature, step): the standardised Normal increments of 4 096 chains x 4 temperatures x
+    dim 30 over 4 steps are N(0, 1) (Kolmogorov-Smirnov, kurtosis), the accept uniforms are U(0, 1), and neighbouring
+    chains, temperatures, steps and dimensions are uncorrelated."""
+    from scipy import stats
+
+    Cn, T, D, steps = 4096, 4, 30, 4
+    f32 = np.float32
+    beta = np.array([1.0, 0.5, 0.2, 0.05], f32)
+    prop = H.proposal_spec("Normal", D, beta, base_variance_scalar=0.37)
+    zeros = torch.zeros(Cn, T, D, device=device)
+    plan = E.RunPlan(None, prop.engine(device), state=zeros, logp=torch.zeros(Cn, T, device=device), beta=dev_t(beta, device),
+                     seed=20240607, chain_offset=123456789)
+    z, u = [], []
+    for s in range(steps):
+        props = plan.split_propose(s)  # state is zero: the proposals are the increments
+        z.append((props / dev_t(prop.temp_scale, device)[None, :, None]).cpu().numpy().astype(np.float64))
+        u.append(plan._split_buffers()[1].cpu().numpy().astype(np.float64))
+    z, u = np.stack(z), np.stack(u)  # [steps, C, T, D], [steps, C, T]
+    n = z.size
+    assert stats.kstest(z.ravel(), "norm").pvalue > 1e-4
+    assert abs(z.mean()) < 5 / np.sqrt(n) and abs(z.var() - 1.0) < 5 * np.sqrt(2.0 / n)
+    assert abs(stats.kurtosis(z.ravel())) < 5 * np.sqrt(24.0 / n)
+    assert stats.kstest(u.ravel(), "uniform").pvalue > 1e-4
+    assert u.min() >= 0.0 and u.max() < 1.0
+
+    def corr(a, b):
+        return abs(np.corrcoef(a.ravel(), b.ravel())[0, 1])
+
+    lim = lambda m: 5.0 / np.sqrt(m)  # noqa: E731  (five standard errors of a sample correlation)
+    assert corr(z[:, :-1], z[:, 1:]) < lim(z[:, 1:].size)              # neighbouring chains
+    assert corr(z[:, :, :-1], z[:, :, 1:]) < lim(z[:, :, 1:].size)      # neighbouring temperatures
+    assert corr(z[:-1], z[1:]) < lim(z[1:].size)                        # consecutive steps
+    assert corr(z[..., :-1], z[..., 1:]) < lim(z[..., 1:].size)         # neighbouring dimensions (incl. Box-Muller pairs)
+    assert corr(z[..., 0::2] ** 2, z[..., 1::2] ** 2) < lim(z[..., 0::2].size)  # the two outputs of a pair, second moments
+    assert corr(u, z[..., 0]) < lim(u.size) and corr(u, z[..., -1]) < lim(u.size)  # accept uniform vs its step's normals
+    assert corr(u[:, :-1], u[:, 1:]) < lim(u[:, 1:].size)
