@@ -19,7 +19,7 @@ STUB(hypercube_variants) STUB(neal_funnel_variants)
 EOS
 # the flags given on the command line go to the NARROW width group (the one the Makefile's SCHED applies to); the WIDE
 # group and capi.hip are built with the defaults, as in the Makefile
-BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function"
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $PTRWM_EXP_ALL_FLAGS"  # PTRWM_EXP_ALL_FLAGS: every unit
 /opt/rocm/bin/hipcc $BASE -c capi.hip -o $OBJ/capi.o &
 /opt/rocm/bin/hipcc $BASE -c $OBJ/stubs.hip -o $OBJ/stubs.o &
 for v in rough_carpet rough_carpet2; do
