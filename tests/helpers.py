@@ -279,6 +279,23 @@ def _prove_mh_flip(r, l_x, l_y, beta_t, u, slack, where):
     return gap / max(thr * tol_r + 6e-8, 1e-300)
 
 
+def _prove_edge_flip(spec, x_t, y_t, l_x, l_y, rtol, where):
+    """The other legitimate kind of Metropolis flip, possible only where the proposals are compared with a tolerance
+    (Laplace / UniformRadius, or any proposal in Philox mode; never with exact_states): the proposal lands within that
+    tolerance of the EDGE of the target's support (IIDGamma x > 0, IIDBeta 0 < x < 1, Hypercube), so one engine's
+    proposal is inside (finite log-density) and the other's outside (-inf, rejected).  Proof: moving the oracle's
+    proposal by delta = rtol max(|x|, |y|) per coordinate, towards either side, changes whether its log-density is
+    finite.  A proposal that is clearly inside or clearly outside the support proves nothing and fails."""
+    assert np.isfinite(l_x), f"{where}: the current state has a non-finite log-density ({l_x})"
+    x64, y64 = np.asarray(x_t, np.float64), np.asarray(y_t, np.float64)
+    delta = rtol * np.maximum(np.abs(x64), np.abs(y64))
+    near = O.logdensity(spec.oracle(), np.stack([y64 + delta, y64 - delta]).astype(f32), "f64")
+    assert bool(np.any(np.isfinite(near) != np.isfinite(l_y))), \
+        f"{where}: WRONG Metropolis decision: the proposal is not within {rtol:g} (relative) of the edge of the support " \
+        f"(l' = {l_y}, at y +- delta: {near.tolist()})"
+    return 0.0
+
+
 def _prove_swap_flip(lm, beta, us, swap_mode, swap_order, ev_number, slack, where, in_band=None):
     """Replays one swap event along the oracle's path in fp64 and asserts that at least one attempted pair has its
     uniform inside the tolerance band of its threshold (so a different outcome is an fp32-level flip).
@@ -377,9 +394,19 @@ def check_parity(run_a, run_b, spec, prop, *, state, logp, beta, n_steps, burn_i
         swap_due = T > 1 and sc > burn_in and sc % swap_every == 0
         if fl[d]:
             for t in np.nonzero(got["accept_flags"][d, c] != want["accept_flags"][d, c])[0]:
-                m = _prove_mh_flip(float(r[t]), float(l_x[t]), float(l_y[t]), beta[t], ext_u[d, c, t], slack,
-                                   f"{where}, temperature {t}")
-                flips.append((s_glob, c, "mh", m))
+                wt = f"{where}, temperature {t}"
+                try:
+                    m = _prove_mh_flip(float(r[t]), float(l_x[t]), float(l_y[t]), beta[t], ext_u[d, c, t], slack, wt)
+                    kind = "mh"
+                except AssertionError as band_error:
+                    if exact_states:  # proposals are bit-identical: the edge of the support cannot separate them
+                        raise
+                    try:
+                        m = _prove_edge_flip(spec, pre_x[t], y[t], float(l_x[t]), float(l_y[t]), state_rtol, wt)
+                    except AssertionError as edge_error:
+                        raise AssertionError(f"{band_error}; and {edge_error}") from None
+                    kind = "mh-edge"
+                flips.append((s_glob, c, kind, m))
         else:
             assert swap_due, f"{where}: states differ although every decision agrees and no swap is due"
             acc = want["accept_flags"][d, c].astype(bool)

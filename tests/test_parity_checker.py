@@ -185,3 +185,72 @@ def test_an_invisible_swap_flip_must_be_provable():
 
     flips = H.check_parity(run_b, run, spec, prop, **kw)
     assert ("swap-invisible" in [f[2] for f in flips]) and out2["swap_accept"].shape == base["swap_accept"].shape
+
+
+def _edge_case():
+    """IIDGamma (shape 1: the density is finite right up to the edge x = 0) with a Laplace proposal, whose states are
+    compared with a tolerance.  Returns the case and the two neighbouring lattice uniforms of (step 3, ladder 0,
+    temperature 0, coordinate 0) between which the proposal's first coordinate changes sign."""
+    D, T, Cn, N, s0 = 3, 2, 2, 8, 3
+    spec = H.spec_from_params("IIDGammaTorch", D, {"shape": f32(1.0), "scale": f32(1.0)})
+    beta = np.array([1.0, 0.5], f32)
+    prop = H.proposal_spec("Laplace", D, beta, base_variance_vector=np.full(D, 2.0, f32))
+    rng = np.random.default_rng(5)
+    st = np.full((Cn, T, D), 1.0, f32)
+    lp = np.broadcast_to(O.logdensity(spec.oracle(), st[0, :1]).astype(f32), (Cn, T)).copy()
+    ext = (0.5 + 0.02 * (rng.random((N, Cn, T, D)) - 0.5)).astype(f32)  # small moves: the chain stays near 1
+    kw = dict(state=st, logp=lp, beta=beta, n_steps=N, burn_in=0, swap_every=4, ext_prop=ext,
+              ext_u=rng.random((N, Cn, T)).astype(f32), ext_swap_u=rng.random((N // 4, Cn, T - 1)).astype(f32),
+              exact_states=False, state_rtol=2e-5, state_atol=2e-5)
+    run = H.oracle_runner(spec, prop)
+    base = run(state=st, logp=lp, beta=beta, step0=0, n_steps=s0, burn_in=0, swap_every=4, swap_mode=0, swap_order=0,
+               ext_prop=ext[:s0], ext_u=kw["ext_u"][:s0], ext_swap_u=kw["ext_swap_u"])
+    x = base["trace"][s0 - 1, 0]  # [T, D] state before step s0
+    scale = float(prop.dim_scale[0]) * float(prop.temp_scale[0])
+    u_star = 0.5 - (1.0 - np.exp(-float(x[0, 0]) / scale)) / 2.0  # increment = -x: the proposal lands on 0
+    cands = (np.round(u_star * 2**24) + np.arange(-16, 17)) * 2.0**-24
+    rows = np.repeat(ext[s0, 0][None], len(cands), axis=0)
+    rows[:, 0, 0] = cands.astype(f32)
+    y0 = np.array([H.step_log_ratios(spec, prop, x, r, beta)[3][0, 0] for r in rows])
+    k = int(np.nonzero((y0[:-1] <= 0) != (y0[1:] <= 0))[0][0])
+    u_out, u_in = (cands[k], cands[k + 1]) if y0[k] <= 0 else (cands[k + 1], cands[k])
+    kw["ext_u"][s0, 0, 0] = f32(1e-6)  # whoever sees a finite log-density accepts
+    return spec, prop, kw, run, s0, f32(u_in), f32(u_out)
+
+
+def test_a_proposal_on_the_edge_of_the_support_is_a_provable_flip():
+    """Found by the randomised runs (IIDGamma / UniformRadius): two engines whose proposals agree to the stated tolerance
+    can land on different sides of x = 0 - one sees -inf and rejects, the other accepts.  Legitimate only when the
+    proposal is within that tolerance of the edge; check_parity proves it and resynchronises."""
+    spec, prop, kw, run, s0, u_in, u_out = _edge_case()
+    kw["ext_prop"][s0, 0, 0, 0] = u_out  # the reference side: just outside, -inf, rejected
+
+    def run_a(**k):  # the other engine: one lattice step away, just inside, accepted
+        k = dict(k)
+        i = s0 - k["step0"]
+        if 0 <= i < k["n_steps"] and k["state"].shape[0] == kw["state"].shape[0]:
+            k["ext_prop"] = k["ext_prop"].copy()
+            k["ext_prop"][i, 0, 0, 0] = u_in
+        return run(**k)
+
+    flips = H.check_parity(run_a, run, spec, prop, **kw)
+    assert [f[:3] for f in flips] == [(s0, 0, "mh-edge")]
+    # with bit-identical proposals (exact_states) the edge cannot separate two engines: the same difference must fail
+    with pytest.raises(AssertionError, match="not an fp32-level flip"):
+        H.check_parity(run_a, run, spec, prop, **{**kw, "exact_states": True})
+
+
+def test_a_decision_flip_far_from_the_edge_of_the_support_fails():
+    spec, prop, kw, run, s0, u_in, u_out = _edge_case()
+    kw["ext_prop"][s0, 0, 0, 0] = f32(0.02)  # the reference side: far outside the support (x_0 < -1), rejected
+
+    def run_a(**k):  # the other engine ignores that and moves somewhere legal: a wrong decision
+        k = dict(k)
+        i = s0 - k["step0"]
+        if 0 <= i < k["n_steps"] and k["state"].shape[0] == kw["state"].shape[0]:
+            k["ext_prop"] = k["ext_prop"].copy()
+            k["ext_prop"][i, 0, 0, 0] = f32(0.5)
+        return run(**k)
+
+    with pytest.raises(AssertionError, match="WRONG Metropolis decision"):
+        H.check_parity(run_a, run, spec, prop, **kw)
