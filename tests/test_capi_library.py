@@ -214,3 +214,25 @@ def test_a_compiled_caller_links_and_validates_without_python(engine):
     names = [ln.split()[0] for ln in libs.splitlines() if ln.strip()]  # sonames (the tree's own path contains "pytorch")
     assert any(n.startswith("libptrwm_hip.so") for n in names)
     assert not any("torch" in n or "python" in n.lower() or n.startswith("libc10") for n in names), names
+
+
+def test_the_binding_stub_printed_in_integration_md_has_the_c_layout(engine):
+    """INTEGRATION.md section B shows the ctypes stub a maintainer of the reference would add.  Documentation drifts:
+    execute that very block (library path patched to the built library) and compare its three structures, field by field,
+    with the product binding's mirrors, which test_struct_layouts_match_the_c_header pins to the C header."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# algorithms/_ptrwm\.py.*?)```", text, flags=re.S).group(1)
+    assert 'C.CDLL("libptrwm_hip.so")' in block
+    ns = {}
+    exec(block.replace('C.CDLL("libptrwm_hip.so")', f"C.CDLL({engine.LIB_PATH!r})"), ns)
+    for name in ("TargetDesc", "ProposalDesc", "RunArgs"):
+        doc, ref = ns[name], getattr(engine, name)
+        assert C.sizeof(doc) == C.sizeof(ref), name
+        assert [f[0] for f in doc._fields_] == [f[0] for f in ref._fields_], name
+        for f, *_ in ref._fields_:
+            assert getattr(doc, f).offset == getattr(ref, f).offset and getattr(doc, f).size == getattr(ref, f).size, (name, f)
+    assert ns["lib"].ptrwm_run.restype is C.c_int32
+    # the call shown in the second block uses only fields that exist
+    call = re.search(r"```python\n(t = TargetDesc\(kind=0.*?)```", text, flags=re.S).group(1)
+    used = set(re.findall(r"[(,\s](\w+)=", re.search(r"a = RunArgs\((.*?)\)\nrc", call, flags=re.S).group(1)))
+    assert used <= {f[0] for f in engine.RunArgs._fields_}, used - {f[0] for f in engine.RunArgs._fields_}
