@@ -1006,3 +1006,23 @@ def test_a_compiled_caller_runs_the_c_abi_without_python_or_torch(device):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "capi host test ok" in out.stdout
     assert out.stdout.count("ladders identical to the oracle") == 4
+
+
+def test_the_example_printed_in_the_readme_runs(device, capsys):
+    """README.md's usage example, executed as printed (batch and run length scaled down so it takes a second)."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "README.md")).read()
+    block = re.search(r"```python\n(import sys; sys\.path\.insert.*?)```", text, flags=re.S).group(1)
+    assert "num_replicas=65536" in block and "generate_samples(10_000)" in block
+    block = block.replace("num_replicas=65536", "num_replicas=512").replace("generate_samples(10_000)", "generate_samples(500)")
+    block = block.replace('sys.path.insert(0, "rwm-pt-pytorch_amd")', f'sys.path.insert(0, {os.path.join(root, "rwm-pt-pytorch_amd")!r})')
+    ns = {}
+    exec(block, ns)
+    assert tuple(ns["cold"].shape) == (500, 30) and ns["cold"].is_cuda
+    assert "0." in capsys.readouterr().out  # the example prints its three statistics
+    pt = ns["pt"]
+    assert 0.5 < pt.swap_acceptance_rate < 0.9 and pt.expected_squared_jump_distance_gpu() > 0.0
+    assert len(pt.mh_acceptance_rates()) == 32
