@@ -1026,3 +1026,26 @@ def test_the_example_printed_in_the_readme_runs(device, capsys):
     pt = ns["pt"]
     assert 0.5 < pt.swap_acceptance_rate < 0.9 and pt.expected_squared_jump_distance_gpu() > 0.0
     assert len(pt.mh_acceptance_rates()) == 32
+
+
+def test_the_example_scripts_run(device):
+    """examples/pt_multi_gpu.py (one rank, a small job) and examples/custom_target.py (a user-defined density in split
+    steps) as a user would start them: fresh processes, their own sys.path set-up."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "pt_multi_gpu.py"), "--ladders", "512", "--temps", "8",
+                          "--dim", "10", "--steps", "300", "--burn-in", "50"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "1 GPU(s), 512 ladders x 8 temps x 350 steps" in out.stdout
+    m = re.search(r"swap acceptance ([0-9.]+)", out.stdout)
+    assert m and 0.05 < float(m.group(1)) < 0.95
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "custom_target.py")], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"mean radius ([0-9.]+)", out.stdout)
+    assert m and abs(float(m.group(1)) - 4.0) < 0.25, out.stdout
