@@ -142,6 +142,25 @@ def propose(proposal: Proposal, dim, n, seed=0, ext_raw=None, precision="f32"):
     return out
 
 
+def philox_randoms(proposal_kind, dim, n_temps, n_chains, *, seed, step0, n_steps, burn_in=0, swap_every=1,
+                   chain_offset=0):
+    """The raw randoms the oracle's Philox mode consumes for this step range, as external-randoms arrays
+    (oracle_philox_randoms): ext_prop [n, C, T, raw], ext_u [n, C, T], ext_swap_u [events, C, T-1] (None for T == 1).
+    `run(..., ext_prop=, ext_u=, ext_swap_u=)` with them equals `run(..., seed=)` bit for bit."""
+    raw = ext_raw_per_step(proposal_kind, dim)
+    ext_prop = np.zeros((n_steps, n_chains, n_temps, raw), dtype=np.float32)
+    ext_u = np.zeros((n_steps, n_chains, n_temps), dtype=np.float32)
+    n_ev = max(0, (step0 + n_steps) // swap_every - burn_in // swap_every) - max(0, step0 // swap_every - burn_in // swap_every)
+    ext_swap_u = np.zeros((n_ev, n_chains, n_temps - 1), dtype=np.float32) if n_temps > 1 else None
+    fn = lib().oracle_philox_randoms
+    fn.restype = C.c_int32
+    rc = fn(C.c_int32(proposal_kind), C.c_int32(dim), C.c_int32(n_temps), C.c_int64(n_chains), C.c_int64(chain_offset),
+            C.c_uint64(seed & (2**64 - 1)), C.c_int64(step0), C.c_int64(n_steps), C.c_int64(burn_in), C.c_int32(swap_every),
+            C.c_void_p(ext_prop.ctypes.data), C.c_void_p(ext_u.ctypes.data), C.c_void_p(_ptr(ext_swap_u)))
+    assert rc == 0, rc
+    return ext_prop, ext_u, ext_swap_u
+
+
 def run(target: Target, proposal: Proposal, *, state, logp, beta, step0, n_steps, burn_in=0, swap_every=1,
         swap_mode=SWAP_EXCHANGE, swap_order=ORDER_SEQUENTIAL, seed=0, chain_offset=0, ext_prop=None, ext_u=None,
         ext_swap_u=None, trace_chains=0, trace_temps=0, want_flags=False, precision="f32", swap_event_offset=0):

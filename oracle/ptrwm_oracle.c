@@ -105,3 +105,69 @@ int32_t oracle_ext_raw_per_step(int32_t kind, int32_t dim) {
 #define R_POW pow
 #define R_FABS fabs
 #include "ptrwm_oracle_body.inc"
+#undef REAL
+#undef SFX
+#undef R_EXP
+#undef R_LOG
+#undef R_LOG1P
+#undef R_SQRT
+#undef R_POW
+#undef R_FABS
+
+/* The raw randoms oracle_run_f32 consumes in Philox mode (ext_prop == NULL), written out in the layout of the
+ * external-randoms arrays of include/ptrwm.h, so that oracle_run_f32 driven with these arrays performs the SAME
+ * float operations as its Philox mode (asserted bit for bit by tests/test_parity_checker.py).  This is what lets
+ * tests/helpers.check_parity PROVE every decision on which the HIP kernel's in-kernel Philox path differs from the
+ * oracle: the proof needs the step's proposal randoms and uniforms as numbers.
+ *   ext_prop   [n_steps, n_chains, n_temps, raw]  NORMAL: the Box-Muller normals z; LAPLACE: the [0,1) uniforms;
+ *                                                 UNIFORM_RADIUS: z[dim] then the radius uniform
+ *   ext_u      [n_steps, n_chains, n_temps]       accept uniforms
+ *   ext_swap_u [events, n_chains, n_temps - 1]    swap uniforms of the events of this step range (may be NULL)
+ * Word map: rwm-pt-pytorch_amd/csrc/proposals.h header comment, as propose_one() above follows it. */
+int32_t oracle_philox_randoms(int32_t proposal_kind, int32_t dim, int32_t n_temps, int64_t n_chains, int64_t chain_offset,
+                              uint64_t seed, int64_t step0, int64_t n_steps, int64_t burn_in, int32_t swap_every,
+                              float *ext_prop, float *ext_u, float *ext_swap_u) {
+  const int n_raw = oracle_ext_raw_per_step(proposal_kind, dim);
+  if (n_raw < 0) return n_raw;
+  if (!ext_prop || !ext_u) return PTRWM_E_NULL;
+  if (swap_every < 1) return PTRWM_E_ARG;
+  const int T = n_temps, D = dim;
+  const int w_even = 2 * ((D + 1) / 2);
+  const int64_t se = swap_every;
+  int64_t ev = 0; /* events of this call so far */
+  for (int64_t i = 0; i < n_steps; ++i) {
+    const uint64_t s = (uint64_t)(step0 + i);
+    const int64_t sc = step0 + i + 1;
+    const int swap_due = T > 1 && sc > burn_in && (sc % se == 0);
+    for (int64_t c = 0; c < n_chains; ++c) {
+      const uint64_t g = (uint64_t)(chain_offset + c);
+      for (int t = 0; t < T; ++t) {
+        const int64_t srep = (i * n_chains + c) * T + t;
+        float *raw = ext_prop + srep * n_raw;
+        if (proposal_kind == PTRWM_PROPOSAL_LAPLACE) {
+          for (int d = 0; d < D; ++d) raw[d] = u01f(philox_word(seed, 0, s, g, (uint32_t)t, (uint32_t)d));
+          ext_u[srep] = u01f(philox_word(seed, 0, s, g, (uint32_t)t, (uint32_t)D));
+        } else {
+          for (int d = 0; d < D; d += 2) {
+            float z0, z1;
+            box_muller_f32(philox_word(seed, 0, s, g, (uint32_t)t, (uint32_t)d),
+                           philox_word(seed, 0, s, g, (uint32_t)t, (uint32_t)d + 1), &z0, &z1);
+            raw[d] = z0;
+            if (d + 1 < D) raw[d + 1] = z1;
+          }
+          if (proposal_kind == PTRWM_PROPOSAL_UNIFORM_RADIUS) {
+            raw[D] = u01f(philox_word(seed, 0, s, g, (uint32_t)t, (uint32_t)w_even));
+            ext_u[srep] = u01f(philox_word(seed, 0, s, g, (uint32_t)t, (uint32_t)w_even + 1));
+          } else {
+            ext_u[srep] = u01f(philox_word(seed, 0, s, g, (uint32_t)t, (uint32_t)w_even));
+          }
+        }
+      }
+      if (swap_due && ext_swap_u)
+        for (int j = 0; j < T - 1; ++j)
+          ext_swap_u[(ev * n_chains + c) * (T - 1) + j] = u01f(philox_word(seed, 1, s, g, (uint32_t)j, 0));
+    }
+    if (swap_due) ++ev;
+  }
+  return PTRWM_OK;
+}

@@ -286,7 +286,9 @@ def _prove_edge_flip(spec, x_t, y_t, l_x, l_y, rtol, where):
     proposal is inside (finite log-density) and the other's outside (-inf, rejected).  Proof: moving the oracle's
     proposal by delta = rtol max(|x|, |y|) per coordinate, towards either side, changes whether its log-density is
     finite.  A proposal that is clearly inside or clearly outside the support proves nothing and fails."""
-    assert np.isfinite(l_x), f"{where}: the current state has a non-finite log-density ({l_x})"
+    # (a current state outside the support, l = -inf, is allowed: the rule then accepts exactly the proposals with a
+    # finite log-density - r = +inf - so the decision still turns on which side of the edge the proposal falls)
+    assert np.isfinite(l_x) or l_x == -np.inf, f"{where}: the current state has log-density {l_x}"
     x64, y64 = np.asarray(x_t, np.float64), np.asarray(y_t, np.float64)
     delta = rtol * np.maximum(np.abs(x64), np.abs(y64))
     near = O.logdensity(spec.oracle(), np.stack([y64 + delta, y64 - delta]).astype(f32), "f64")
@@ -332,9 +334,11 @@ def _prove_swap_flip(lm, beta, us, swap_mode, swap_order, ev_number, slack, wher
 
 def check_parity(run_a, run_b, spec, prop, *, state, logp, beta, n_steps, burn_in, swap_every, swap_mode=O.SWAP_EXCHANGE,
                  swap_order=O.ORDER_SEQUENTIAL, ext_prop, ext_u, ext_swap_u=None, exact_states, step0=0, slack=1.0,
-                 state_rtol=1e-4, state_atol=2e-5, max_flip_rate=1e-3, _depth=0, _flips=None):
+                 state_rtol=1e-4, state_atol=2e-5, max_flip_rate=1e-3, chain_offset=0, _depth=0, _flips=None):
     """run_a / run_b: callables(**kw) -> dict with trace [n, C, T, D], trace_logp [n, C, T], accept_flags [n, C, T],
     n_accept, sq_jump, swap_accept, last_swap_ordinal (engine A = the one under test, B = the oracle).
+    chain_offset: global id of ladder 0 (the Philox subsequence): passed to both engines and advanced when a single
+    ladder is restarted, so an engine that draws its randoms from (seed, step, chain) stays on its stream.
     Returns the list of proven flips [(global step, ladder, kind, margin in tolerance bands)]."""
     flips = [] if _flips is None else _flips
     state = np.ascontiguousarray(state, dtype=f32)
@@ -345,7 +349,7 @@ def check_parity(run_a, run_b, spec, prop, *, state, logp, beta, n_steps, burn_i
         slack = slack * 2.0  # the increments themselves differ by <= 2 ulp between the engines
     kw = dict(state=state, logp=logp, beta=beta, step0=step0, n_steps=n_steps, burn_in=burn_in, swap_every=swap_every,
               swap_mode=swap_mode, swap_order=swap_order, ext_prop=ext_prop, ext_u=ext_u,
-              ext_swap_u=ext_swap_u if T > 1 else None)
+              ext_swap_u=ext_swap_u if T > 1 else None, chain_offset=chain_offset)
     got, want = run_a(**kw), run_b(**kw)
     ev0 = events_upto(step0, swap_every, burn_in)
     for c in range(Cn):
@@ -425,8 +429,8 @@ def check_parity(run_a, run_b, spec, prop, *, state, logp, beta, n_steps, burn_i
                          ext_u=np.ascontiguousarray(ext_u[d + 1:, c:c + 1]),
                          ext_swap_u=None if ext_swap_u is None else np.ascontiguousarray(ext_swap_u[ev_next:, c:c + 1]),
                          exact_states=exact_states, step0=sc, slack=slack / (1.0 if exact_states else 2.0),
-                         state_rtol=state_rtol, state_atol=state_atol, max_flip_rate=max_flip_rate, _depth=_depth + 1,
-                         _flips=flips)
+                         state_rtol=state_rtol, state_atol=state_atol, max_flip_rate=max_flip_rate,
+                         chain_offset=chain_offset + c, _depth=_depth + 1, _flips=flips)
     if _depth == 0:
         budget = 3 + max_flip_rate * n_steps * Cn * T
         assert len(flips) <= budget, f"{len(flips)} decision flips in {n_steps * Cn * T} decisions: too many for fp32 " \
@@ -440,3 +444,130 @@ def oracle_runner(spec, prop, precision="f32"):
         Cn, T = kw["state"].shape[:2]
         return O.run(spec.oracle(), prop.oracle(), trace_chains=Cn, trace_temps=T, want_flags=True, precision=precision, **kw)
     return run
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The HIP engine as a runner (GPU tests, tools/, __graft_entry__.smoke)
+# ---------------------------------------------------------------------------------------------------------
+def dev_t(a, device, dtype=None):
+    import torch
+
+    dtype = torch.float32 if dtype is None else dtype
+    return torch.tensor(np.ascontiguousarray(a), device=device, dtype=dtype)
+
+
+def gpu_run(spec, prop, device, *, state, logp, beta, n_steps, trace_temps=0, want_flags=False, ext_prop=None,
+            ext_u=None, ext_swap_u=None, **kw):
+    """Mirror of oracle.run for the HIP engine, through its C ABI (ptrwm_hip.run): returns numpy results."""
+    import torch
+
+    import ptrwm_hip as E
+
+    Cn, T, D = state.shape
+    st, lp = dev_t(state, device), dev_t(logp, device).reshape(Cn, T).contiguous()
+    res = {
+        "n_accept": torch.zeros(Cn, T, dtype=torch.int64, device=device),
+        "sq_jump": torch.zeros(Cn, T, dtype=torch.float64, device=device),
+        "swap_accept": torch.zeros(Cn, T, dtype=torch.int64, device=device),
+        "last_swap_ordinal": torch.zeros(Cn, T, dtype=torch.int64, device=device),
+    }
+    trace = trace_logp = flags = None
+    if trace_temps:
+        trace = torch.zeros(n_steps, Cn, trace_temps, D, device=device)
+        trace_logp = torch.zeros(n_steps, Cn, trace_temps, device=device)
+    if want_flags:
+        flags = torch.zeros(n_steps, Cn, T, dtype=torch.uint8, device=device)
+    E.run(spec.engine(device), prop.engine(device), state=st, logp=lp, beta=dev_t(beta, device), n_steps=n_steps,
+          n_accept=res["n_accept"], sq_jump=res["sq_jump"], swap_accept=res["swap_accept"],
+          last_swap_ordinal=res["last_swap_ordinal"], trace=trace, trace_logp=trace_logp, accept_flags=flags,
+          ext_prop=None if ext_prop is None else dev_t(ext_prop, device),
+          ext_u=None if ext_u is None else dev_t(ext_u, device),
+          ext_swap_u=None if ext_swap_u is None else dev_t(ext_swap_u, device), **kw)
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy() for k, v in res.items()}
+    out["state"], out["logp"] = st.cpu().numpy(), lp.cpu().numpy()
+    if trace is not None:
+        out["trace"], out["trace_logp"] = trace.cpu().numpy(), trace_logp.cpu().numpy()
+    if flags is not None:
+        out["accept_flags"] = flags.cpu().numpy()
+    return out
+
+
+def gpu_runner(spec, prop, device):
+    """run_a for helpers.check_parity: the HIP engine through the C ABI, per-step trace and accept flags on."""
+    def run(**kw):
+        return gpu_run(spec, prop, device, trace_temps=kw["state"].shape[1], want_flags=True, **kw)
+    return run
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The same comparison for the PRODUCTION path: the kernel draws its randoms itself (Philox, in-kernel Box-Muller with the
+# hardware sin / cos, the per-temperature scale folded into the radius), the oracle restates the same counter layout
+# and exports the numbers it drew (oracle_philox_randoms), so every differing decision can be proven exactly as above.
+# ---------------------------------------------------------------------------------------------------------
+def philox_runner(run, seed):
+    """run_a for check_parity from an engine runner: the external-randoms arrays are dropped, the engine draws from
+    Philox(seed, step, chain_offset + chain) itself."""
+    def run_a(**kw):
+        kw = {k: v for k, v in kw.items() if k not in ("ext_prop", "ext_u", "ext_swap_u")}
+        return run(seed=seed, **kw)
+    return run_a
+
+
+def check_parity_philox(run, spec, prop, *, state, logp, beta, n_steps, burn_in, swap_every, seed, chain_offset=0, step0=0,
+                        swap_mode=O.SWAP_EXCHANGE, swap_order=O.ORDER_SEQUENTIAL, segment=None, **tol):
+    """Full-horizon parity of an engine in Philox mode (`run(seed=, chain_offset=, step0=, ...)`) with the oracle on the
+    same stream: every differing Metropolis / swap decision PROVEN (check_parity), bookkeeping identical on agreeing
+    segments, states equal to the stated tolerance at every step.  The two engines agree on the proposals only to a few
+    ulp (hardware sin / cos / log against libm), so states are compared with a tolerance (`exact_states=False`) and, if
+    `segment` is given, both engines restart from the oracle's own trajectory every `segment` steps so that rounding
+    drift cannot build up over a long horizon.  Returns the proven flips."""
+    state = np.ascontiguousarray(state, dtype=f32)
+    Cn, T, D = state.shape
+    logp = np.ascontiguousarray(logp, dtype=f32).reshape(Cn, T)
+    ext_prop, ext_u, ext_swap_u = O.philox_randoms(prop.kind, D, T, Cn, seed=seed, step0=step0, n_steps=n_steps,
+                                                   burn_in=burn_in, swap_every=swap_every, chain_offset=chain_offset)
+    run_a, run_b = philox_runner(run, seed), oracle_runner(spec, prop)
+    common = dict(beta=beta, burn_in=burn_in, swap_every=swap_every, swap_mode=swap_mode, swap_order=swap_order,
+                  chain_offset=chain_offset, exact_states=False, **tol)
+    if segment is None or segment >= n_steps:
+        return check_parity(run_a, run_b, spec, prop, state=state, logp=logp, n_steps=n_steps, step0=step0,
+                            ext_prop=ext_prop, ext_u=ext_u, ext_swap_u=ext_swap_u, **common)
+    path = run_b(state=state, logp=logp, beta=np.asarray(beta, f32), step0=step0, n_steps=n_steps, burn_in=burn_in,
+                 swap_every=swap_every, swap_mode=swap_mode, swap_order=swap_order, ext_prop=ext_prop, ext_u=ext_u,
+                 ext_swap_u=ext_swap_u, chain_offset=chain_offset)  # the oracle's own trajectory
+    flips = []
+    ev0 = events_upto(step0, swap_every, burn_in)
+    for a in range(0, n_steps, segment):
+        n = min(segment, n_steps - a)
+        e0 = events_upto(step0 + a, swap_every, burn_in) - ev0
+        flips += check_parity(run_a, run_b, spec, prop, state=state if a == 0 else path["trace"][a - 1],
+                              logp=logp if a == 0 else path["trace_logp"][a - 1], n_steps=n, step0=step0 + a,
+                              ext_prop=np.ascontiguousarray(ext_prop[a:a + n]), ext_u=np.ascontiguousarray(ext_u[a:a + n]),
+                              ext_swap_u=None if ext_swap_u is None else np.ascontiguousarray(ext_swap_u[e0:]), **common)
+    return flips
+
+
+def check_production_ladders(device, spec, prop, produced, *, state, beta, n_steps, burn_in, swap_every, seed,
+                             chain_offset=0, swap_mode=O.SWAP_EXCHANGE, swap_order=O.ORDER_SEQUENTIAL, segment=30):
+    """The first ladders of a PRODUCTION run (the non-fixture kernel variant, no trace, whatever kernel form the batch size
+    selected) tied to the oracle without any agreement-rate threshold, in two links:
+      1. the fixture variant of the same kernel, run on the same Philox stream over just these ladders with a per-step
+         trace and accept flags attached, reproduces the production run's final states, log-densities and all four
+         statistics BIT FOR BIT (`produced`: dict of the production run's arrays for these ladders);
+      2. that traced run follows the oracle decision for decision over the full horizon, every differing decision
+         proven (check_parity_philox).
+    state: the common starting point [n, T, D]; the starting log-densities are the engine's own (ptrwm_logdensity, the
+    call the sampler classes make), so both runs start from the same bits."""
+    import ptrwm_hip as E
+
+    state = np.ascontiguousarray(state, dtype=f32)
+    logp = E.logdensity(spec.engine(device), dev_t(state.reshape(-1, state.shape[2]), device)).cpu().numpy().reshape(state.shape[:2])
+    kw = dict(state=state, logp=logp, beta=np.asarray(beta, f32), n_steps=n_steps, burn_in=burn_in, swap_every=swap_every,
+              swap_mode=swap_mode, swap_order=swap_order, chain_offset=chain_offset)
+    full = gpu_runner(spec, prop, device)(step0=0, seed=seed, **kw)
+    for k, v in produced.items():
+        v = np.asarray(v)
+        assert v.shape == full[k].shape and np.array_equal(v.view(np.uint8), np.ascontiguousarray(full[k]).view(np.uint8)), \
+            f"production run and its traced fixture twin differ in `{k}`"
+    return check_parity_philox(gpu_runner(spec, prop, device), spec, prop, seed=seed, segment=segment, **kw)

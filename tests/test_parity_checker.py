@@ -254,3 +254,86 @@ def test_a_decision_flip_far_from_the_edge_of_the_support_fails():
 
     with pytest.raises(AssertionError, match="WRONG Metropolis decision"):
         H.check_parity(run_a, run, spec, prop, **kw)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Philox mode (the production path): the oracle exports the numbers it draws, check_parity_philox proves every flip
+# ---------------------------------------------------------------------------------------------------------
+def _philox_case(pkind, T=5, Cn=3, dim=30):
+    spec = H.target_spec("rc15_d30")
+    beta = (0.05 ** (np.arange(T) / max(1, T - 1))).astype(f32)
+    pkw = {"Normal": dict(base_variance_scalar=2.38**2 / dim), "Laplace": dict(base_variance_vector=np.full(dim, 0.2, f32)),
+           "UniformRadius": dict(base_radius=2.5)}[pkind]
+    prop = H.proposal_spec(pkind, dim, beta, **pkw)
+    st = np.zeros((Cn, T, dim), f32)
+    lp = np.broadcast_to(O.logdensity(spec.oracle(), np.zeros((1, dim), f32)).astype(f32), (Cn, T)).copy()
+    return spec, prop, dict(state=st, logp=lp, beta=beta, n_steps=45, burn_in=7, swap_every=4, seed=0xABCDEF0123,
+                            chain_offset=(1 << 33) + 5, step0=11)
+
+
+def _oracle_philox_engine(spec, prop, precision="f32"):
+    def run(**kw):
+        Cn, T = kw["state"].shape[:2]
+        return O.run(spec.oracle(), prop.oracle(), trace_chains=Cn, trace_temps=T, want_flags=True, precision=precision, **kw)
+    return run
+
+
+@pytest.mark.parametrize("pkind", ["Normal", "Laplace", "UniformRadius"])
+@pytest.mark.parametrize("order", [O.ORDER_SEQUENTIAL, O.ORDER_EVEN_ODD])
+def test_the_oracle_in_philox_mode_equals_the_oracle_on_its_exported_randoms(pkind, order):
+    """oracle_philox_randoms writes out exactly the numbers the oracle's Philox mode consumes: both runs are the same
+    float operations, so everything - states, traces, flags, fp64 jump sums, swap bookkeeping - is bit-identical."""
+    spec, prop, kw = _philox_case(pkind)
+    Cn, T, D = kw["state"].shape
+    ep, eu, es = O.philox_randoms(prop.kind, D, T, Cn, seed=kw["seed"], step0=kw["step0"], n_steps=kw["n_steps"],
+                                  burn_in=kw["burn_in"], swap_every=kw["swap_every"], chain_offset=kw["chain_offset"])
+    assert es.shape[0] == H.events_upto(kw["step0"] + kw["n_steps"], 4, 7) - H.events_upto(kw["step0"], 4, 7)
+    run = _oracle_philox_engine(spec, prop)
+    a = run(swap_order=order, **kw)
+    b = run(swap_order=order, ext_prop=ep, ext_u=eu, ext_swap_u=es, **{k: v for k, v in kw.items() if k != "seed"})
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), k
+    assert a["n_accept"].sum() > 0 and a["swap_accept"].sum() > 0
+
+
+@pytest.mark.parametrize("pkind", ["Normal", "Laplace", "UniformRadius"])
+def test_philox_parity_of_the_oracle_with_itself_and_with_its_fp64_twin(pkind):
+    spec, prop, kw = _philox_case(pkind)
+    assert H.check_parity_philox(_oracle_philox_engine(spec, prop), spec, prop, **kw) == []
+    assert H.check_parity_philox(_oracle_philox_engine(spec, prop), spec, prop, segment=16, **kw) == []
+    # an engine with different arithmetic on the same stream (the fp64 oracle: Box-Muller, transforms and densities in
+    # double): whatever differs must be a proven flip, to the end of the horizon
+    flips = H.check_parity_philox(_oracle_philox_engine(spec, prop, "f64"), spec, prop, segment=16, **kw)
+    assert all(f[2] in ("mh", "swap", "swap-invisible", "mh-edge") for f in flips)
+
+
+@pytest.mark.parametrize("slip", ["accept_word", "normal_pair", "swap_word", "chain_id"])
+def test_a_slipped_philox_word_fails(slip):
+    """What the production-path check exists for: an engine whose accept uniform comes from the
+    NEXT Philox word, whose normals are taken one pair late, whose swap uniform is another word of its block, or which
+    numbers its chains from the wrong offset, follows the oracle statistically (same acceptance rate) but not decision
+    for decision - every one of them must FAIL the Philox-mode comparison."""
+    spec, prop, kw = _philox_case("Normal")
+    Cn, T, D = kw["state"].shape
+    args = dict(seed=kw["seed"], step0=kw["step0"], n_steps=kw["n_steps"], burn_in=kw["burn_in"],
+                swap_every=kw["swap_every"])
+    run = _oracle_philox_engine(spec, prop)
+
+    def engine(**k):
+        off, s0, n = k.pop("chain_offset"), k["step0"], k["n_steps"]
+        k.pop("seed")
+        c = k["state"].shape[0]
+        a = dict(args, step0=s0, n_steps=n)
+        ep, eu, es = O.philox_randoms(prop.kind, D, T, c, chain_offset=off + (1 if slip == "chain_id" else 0), **a)
+        if slip == "accept_word":  # word 2 ceil(D/2) + 1 instead of 2 ceil(D/2): the UniformRadius map's accept word
+            eu = O.philox_randoms(O.PROPOSAL_UNIFORM_RADIUS, D, T, c, chain_offset=off, **a)[1]
+        elif slip == "normal_pair":
+            ep = np.roll(ep, 2, axis=-1)
+        elif slip == "swap_word":  # temperature t + 1's block instead of temperature t's
+            es = np.roll(es, 1, axis=-1)
+        return run(ext_prop=ep, ext_u=eu, ext_swap_u=es, chain_offset=off, **k)
+
+    with pytest.raises(AssertionError):
+        H.check_parity_philox(engine, spec, prop, **kw)
+    with pytest.raises(AssertionError):
+        H.check_parity_philox(engine, spec, prop, segment=16, **kw)
