@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PTRWM_ABI_VERSION 1
+#define PTRWM_ABI_VERSION 2
 #define PTRWM_MAX_DIM 104  /* dim-vector lives in VGPRs; widest compiled variant */
 #define PTRWM_MAX_TEMPS 256 /* one ladder lives in one wavefront (<= 64 temps) or one 256-thread workgroup */
 
@@ -61,7 +61,11 @@ enum {
   PTRWM_TARGET_ROUGH_CARPET = 0,
   /* multimodal_torch.py:173-242 ThreeMixtureDistributionTorch (cov = I)
    *   p[0..2] = log_norm_const_k + log_mixing_weight_k (+ log_jacobian if scaled)
-   *   vec0 = means[3*dim] (row-major [3][dim]); vec1 = scaling_factors[dim] or NULL */
+   *   vec0 = means[3*dim] (row-major [3][dim]); vec1 = scaling_factors[dim] or NULL
+   *   ip[0] = 1: the caller DECLARES that the three mean vectors are equal in every coordinate but the first (the
+   *   class's default centres (-5,0,..), (0,..), (5,0,..) and the +-15 centres of experiment_pt_GPU.py:48-52 are): the
+   *   kernel then evaluates the part of |s x - mu_k|^2 the components share once instead of three times (a third of the
+   *   work, same tolerance).  ip[0] = 0: no assumption.  A false declaration gives a wrong density. */
   PTRWM_TARGET_THREE_MIXTURE = 1,
   /* rosenbrock_torch.py:67-84 FullRosenbrockTorch: p[0]=a, p[1]=b, vec0 = mu[dim-1] */
   PTRWM_TARGET_FULL_ROSENBROCK = 2,
@@ -144,6 +148,9 @@ enum {
 int32_t ptrwm_set_kernel_form(int32_t form);
 /* 1 if ptrwm_run has a lane-split variant for (target, proposal, dim, n_temps), else 0. */
 int32_t ptrwm_has_quad_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim, int32_t n_temps);
+/* 1 if ptrwm_run has a one-thread-per-replica variant for (target, proposal, dim), else 0 (never above dim 64).  Where it
+ * returns 0 PTRWM_FORM_THREAD runs the lane-split kernel: a comparison of the two forms is vacuous there. */
+int32_t ptrwm_has_thread_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim);
 
 /* Number of raw random numbers one MH proposal consumes from `ext_prop`
  * (NORMAL: dim normals; LAPLACE: dim uniforms in [0,1); UNIFORM_RADIUS: dim

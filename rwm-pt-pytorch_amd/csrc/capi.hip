@@ -33,12 +33,30 @@ struct VariantPair {
 //                    VGPRs - one wave per SIMD, 8-25 % slower at full batches, 1.8x at small ones - and sat in the
 //                    register regime in which hipcc miscompiled it twice; see variants.h)
 static int g_kernel_form = PTRWM_FORM_AUTO;  // read / written with __atomic builtins (ptrwm_set_kernel_form may race with a launch)
-constexpr long long kSimds = 1024;  // 256 CUs x 4
 
-static const QuadVariants &quad_variants(int kind, bool two_term) {
+// SIMDs of the current device (compute units x 4), asked once per device: the form rule is stated in wavefronts per SIMD,
+// so a partitioned or CU-masked device (or another CDNA part) gets the rule scaled to what it really has.
+static long long device_simds() {
+  constexpr int kMaxDevices = 64;
+  static int cached[kMaxDevices];  // 0 = not asked yet (a race merely asks twice)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 1024;
+  int n = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+  if (n == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    n = 4 * cus;
+    __atomic_store_n(&cached[dev], n, __ATOMIC_RELAXED);
+  }
+  return n;
+}
+
+// alt: the specialised functor of the kind - RoughCarpet2 (the host proved the third mixture term negligible,
+// rough_carpet_two_term) or ThreeMixture1 (the caller declared means that differ in the first coordinate only, ip[0] = 1)
+static const QuadVariants &quad_variants(int kind, bool alt) {
   switch (kind) {
-    case PTRWM_TARGET_ROUGH_CARPET: return two_term ? rough_carpet2_variants_quad() : rough_carpet_variants_quad();
-    case PTRWM_TARGET_THREE_MIXTURE: return three_mixture_variants_quad();
+    case PTRWM_TARGET_ROUGH_CARPET: return alt ? rough_carpet2_variants_quad() : rough_carpet_variants_quad();
+    case PTRWM_TARGET_THREE_MIXTURE: return alt ? three_mixture1_variants_quad() : three_mixture_variants_quad();
     case PTRWM_TARGET_FULL_ROSENBROCK: return full_rosenbrock_variants_quad();
     case PTRWM_TARGET_EVEN_ROSENBROCK: return even_rosenbrock_variants_quad();
     case PTRWM_TARGET_HYBRID_ROSENBROCK: return hybrid_rosenbrock_variants_quad();
@@ -50,11 +68,11 @@ static const QuadVariants &quad_variants(int kind, bool two_term) {
   }
 }
 
-static VariantPair target_variants(int kind, bool two_term = false) {
+static VariantPair target_variants(int kind, bool alt = false) {
 #define PTRWM_PAIR(SYMBOL) VariantPair{&SYMBOL##_narrow(), &SYMBOL##_wide()}
   switch (kind) {
-    case PTRWM_TARGET_ROUGH_CARPET: return two_term ? PTRWM_PAIR(rough_carpet2_variants) : PTRWM_PAIR(rough_carpet_variants);
-    case PTRWM_TARGET_THREE_MIXTURE: return PTRWM_PAIR(three_mixture_variants);
+    case PTRWM_TARGET_ROUGH_CARPET: return alt ? PTRWM_PAIR(rough_carpet2_variants) : PTRWM_PAIR(rough_carpet_variants);
+    case PTRWM_TARGET_THREE_MIXTURE: return alt ? PTRWM_PAIR(three_mixture1_variants) : PTRWM_PAIR(three_mixture_variants);
     case PTRWM_TARGET_FULL_ROSENBROCK: return PTRWM_PAIR(full_rosenbrock_variants);
     case PTRWM_TARGET_EVEN_ROSENBROCK: return PTRWM_PAIR(even_rosenbrock_variants);
     case PTRWM_TARGET_HYBRID_ROSENBROCK: return PTRWM_PAIR(hybrid_rosenbrock_variants);
@@ -74,6 +92,7 @@ static int check_target(const ptrwm_target_desc *t) {
   switch (t->kind) {
     case PTRWM_TARGET_THREE_MIXTURE:
       if (t->vec0 == nullptr) return PTRWM_E_NULL;
+      if (t->ip[0] != 0 && t->ip[0] != 1) return PTRWM_E_ARG;
       break;
     case PTRWM_TARGET_FULL_ROSENBROCK:
       if (t->dim < 2) return PTRWM_E_DIM;
@@ -394,6 +413,13 @@ int32_t ptrwm_has_quad_variant(int32_t target_kind, int32_t proposal_kind, int32
   return qi >= 0 && quad_variants(target_kind, false).run[proposal_kind][qi] != nullptr ? 1 : 0;
 }
 
+int32_t ptrwm_has_thread_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim) {
+  if (target_kind < 0 || target_kind >= PTRWM_TARGET_COUNT) return 0;
+  if (proposal_kind < 0 || proposal_kind >= PTRWM_PROPOSAL_COUNT) return 0;
+  const int dpi = width_index_for_dim(dim);
+  return dim >= 1 && dpi >= 0 && target_variants(target_kind).run(proposal_kind, dpi) != nullptr ? 1 : 0;
+}
+
 int32_t ptrwm_ext_raw_per_step(int32_t proposal_kind, int32_t dim) {
   switch (proposal_kind) {
     case PTRWM_PROPOSAL_NORMAL: return dim;
@@ -437,7 +463,8 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
 
   const int dpi = width_index_for_dim(target->dim);
   if (dpi < 0) return PTRWM_E_DIM;
-  const bool two_term = target->kind == PTRWM_TARGET_ROUGH_CARPET && rough_carpet_two_term(target->p);
+  const bool two_term = (target->kind == PTRWM_TARGET_ROUGH_CARPET && rough_carpet_two_term(target->p)) ||
+                        (target->kind == PTRWM_TARGET_THREE_MIXTURE && target->ip[0] == 1);  // the kind's specialised functor
   RunLaunchFn fn = target_variants(target->kind, two_term).run(proposal->kind, dpi);  // null above width 64
   // lane-split form? (bit-identical results: a speed decision, see g_kernel_form - except above dim 64, where it is the
   // only form)
@@ -450,7 +477,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
       const long long cpw1 = args->n_temps > 64 ? 1 : 64 / args->n_temps;
       const long long waves1 = args->n_temps > 64 ? args->n_chains * ((args->n_temps + 63) / 64)
                                                   : (args->n_chains + cpw1 - 1) / cpw1;
-      const double w = (double)waves1 / (double)kSimds;
+      const double w = (double)waves1 / (double)device_simds();
       bool faster;
       if (target->dim < 16)
         faster = false;  // a lane would own <= 3 dims and most of the quad one Philox block: the thread kernels (dim
@@ -651,7 +678,9 @@ int32_t ptrwm_logdensity(const ptrwm_target_desc *target, const float *x, float 
   if (x == nullptr || out == nullptr) return PTRWM_E_NULL;
   const int dpi = width_index_for_dim(target->dim);
   if (dpi < 0) return PTRWM_E_DIM;
-  const LogpLaunchFn fn = target_variants(target->kind).logp(dpi);
+  // (RoughCarpet: the three-term functor always - the two-term one has the same bits where it applies; ThreeMixture1: a
+  // different summation order, so a target declared that way is evaluated that way everywhere)
+  const LogpLaunchFn fn = target_variants(target->kind, target->kind == PTRWM_TARGET_THREE_MIXTURE && target->ip[0] == 1).logp(dpi);
   if (fn == nullptr) return PTRWM_E_NOVARIANT;
   const hipError_t err = fn(x, out, n, target->dim, make_tparams(target), (hipStream_t)stream);
   return err == hipSuccess ? PTRWM_OK : PTRWM_E_LAUNCH;

@@ -520,9 +520,14 @@ __global__ void __launch_bounds__(kBlockThreads) ptrwm_logdensity_kernel(const f
   out[i] = Target::template logp<true>(y, D, tp);
 }
 
+// The two stand-alone proposal kernels below hold x[DP] and y[DP] in registers: above width 64 they are compiled for two
+// waves per SIMD, i.e. a budget of 256 registers, so that what does not fit goes to scratch (speed is irrelevant here)
+// and not into AGPRs - the build gate (tools/kernel_stats.py --check) admits no kernel with AGPRs or > 256 VGPRs.
+constexpr int standalone_min_waves(int dp) { return dp > 64 ? 2 : 1; }
+
 // ---- standalone proposal kernel (unit parity of the three samplers) ----
 template <class Proposal, int DP>
-__global__ void __launch_bounds__(kBlockThreads) ptrwm_propose_kernel(
+__global__ void __launch_bounds__(kBlockThreads, standalone_min_waves(DP)) ptrwm_propose_kernel(
     float *__restrict__ out, long long n, int D, int T, const float *__restrict__ temp_scale, PParams pp,
     const float *__restrict__ ext_raw, int n_raw_ext, unsigned k0, unsigned k1) {
   const long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
@@ -551,7 +556,7 @@ __global__ void __launch_bounds__(kBlockThreads) ptrwm_propose_kernel(
 // Same Philox words and the same arithmetic as the fused kernel's Proposal::propose call, so a split step driven
 // with the library's own log-density reproduces ptrwm_run bit for bit.
 template <class Proposal, int DP>
-__global__ void __launch_bounds__(kBlockThreads) ptrwm_split_propose_kernel(
+__global__ void __launch_bounds__(kBlockThreads, standalone_min_waves(DP)) ptrwm_split_propose_kernel(
     const float *__restrict__ state, float *__restrict__ proposals, float *__restrict__ accept_u, long long n_chains,
     long long chain_offset, unsigned long long step, int D, int T, const float *__restrict__ temp_scale, PParams pp,
     const float *__restrict__ ext_raw, const float *__restrict__ ext_u, int n_raw_ext, unsigned k0, unsigned k1) {

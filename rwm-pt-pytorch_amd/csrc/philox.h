@@ -176,8 +176,11 @@ __device__ __forceinline__ float div_rn(float a, float b) {
 // (kernel_quad.h) gives one range to each of the four lanes of a replica and combines with two DPP quad permutes.
 // Same operations on the same operands in the same order => bit-identical results, so the choice of kernel (made by
 // the C ABI from the batch size) can never change a trajectory.  The width depends only on the register-width class,
-// which is a function of dim: dim <= 32 -> 8, dim <= 64 -> 16, dim <= 112 -> 28.
-constexpr int canon_width(int dp) { return dp <= 32 ? 8 : (dp <= 64 ? 16 : 28); }
+// which is a function of dim: dim <= 32 -> 8, dim <= 64 -> 16, dim <= 80 -> 20, dim <= 96 -> 24, dim <= 112 -> 28.
+// (Above dim 64 the lane-split kernel is the only fused form and its cost follows 4 W, not dim: with a single class of
+// W = 28 every dim 65..99 paid for 112 dimensions - a 2x drop in throughput from dim 64 to dim 65,
+// profiles/r02_form_sweep.txt - hence the finer classes there.)
+constexpr int canon_width(int dp) { return dp <= 32 ? 8 : (dp <= 64 ? 16 : (dp <= 80 ? 20 : (dp <= 96 ? 24 : 28))); }
 
 __device__ __forceinline__ float tree4_add(const float (&p)[4]) { return add_rn(add_rn(p[0], p[1]), add_rn(p[2], p[3])); }
 __device__ __forceinline__ float tree4_neg_add(const float (&p)[4]) { return -tree4_add(p); }

@@ -234,9 +234,20 @@ struct UniformRadiusProposal {
     const float inv = div_rn(1.0f, safe);
     // per-dimension tests here, not PTRWM_DIM_LOOP: with the two instances of this in-place update per block the
     // optimiser merges them into one with a selected INDEX, which moves y[] to scratch (tools/kernel_stats.py --check)
+    if (ext_raw != nullptr) {
+      // external randoms: the reference's own operation order, (g / n) * r, then x + increment (uniform.py:58-73)
 #pragma unroll
-    for (int d = 0; d < DP; ++d)
-      if (d < D) y[d] = add_rn(x[d], mul_rn(mul_rn(y[d], inv), rad));
+      for (int d = 0; d < DP; ++d)
+        if (d < D) y[d] = add_rn(x[d], mul_rn(mul_rn(y[d], inv), rad));
+    } else {
+      // Philox path (as philox_normal_step folds the scale into the Box-Muller radius): y = x + g (r / n) as ONE fma per
+      // dimension instead of two multiplies and an add; differs from the form above by <= 1 ulp of the increment, below
+      // the hardware sin / cos error of g itself
+      const float k = mul_rn(inv, rad);
+#pragma unroll
+      for (int d = 0; d < DP; ++d)
+        if (d < D) y[d] = fmaf(y[d], k, x[d]);
+    }
     return u_acc;
   }
 };

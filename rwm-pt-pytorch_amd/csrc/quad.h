@@ -4,7 +4,7 @@
 // (profiles/r02_pmc_cfg2.csv: BASELINE configs[1], 65 536 chains x 1 temperature = ONE wave per SIMD, issues at 0.41 of
 // the peak against 0.59 at four waves), and above dim 64 its register arrays (x[], y[]: 2 x dim VGPRs) leave room for
 // one wave per SIMD only.  Here lane q of a quad owns the dimensions [q W, (q+1) W) of its replica (W = canon_width:
-// 8 / 16 / 28 for dim <= 32 / 64 / 112): a quarter of the Philox blocks, of the proposal transforms and of the
+// 8 / 16 / 20 / 24 / 28 for dim <= 32 / 64 / 80 / 96 / 112): a quarter of the Philox blocks, of the proposal transforms and of the
 // log-density terms, 2 W registers for the state, four times the waves for the same batch.
 //
 // Bit-identical to kernel.h by construction: same Philox words (word w of a step is word w whoever computes it), same
@@ -236,9 +236,16 @@ struct QUniformRadius {
     const float safe = nrm > 1e-12f ? nrm : 1.0f;
     const float rad = tscale * hw_exp2(pp.inv_dim * hw_log2(u_rad));
     const float inv = div_rn(1.0f, safe);
+    if (ext_rep != nullptr) {
 #pragma unroll
-    for (int j = 0; j < W; ++j)
-      if (q_valid<MIN_OWN>(l, j)) y[j] = add_rn(x[j], mul_rn(mul_rn(y[j], inv), rad));
+      for (int j = 0; j < W; ++j)
+        if (q_valid<MIN_OWN>(l, j)) y[j] = add_rn(x[j], mul_rn(mul_rn(y[j], inv), rad));
+    } else {  // Philox path: one fma per dimension (see proposals.h)
+      const float k = mul_rn(inv, rad);
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+        if (q_valid<MIN_OWN>(l, j)) y[j] = fmaf(y[j], k, x[j]);
+    }
     return u_acc;
   }
 };
@@ -312,6 +319,46 @@ struct QThreeMixture {
       if ((j & 7) == 7) sched_fence_soft();
     }
     return ThreeMixture<W>::finish(quad_tree_add(q0), quad_tree_add(q1), quad_tree_add(q2), tp);
+  }
+  __device__ __forceinline__ static float logp(const float (&y)[W], const QLane &l, int D, const TParams &tp) {
+    return tp.vec1 != nullptr ? impl<true>(y, l, D, tp) : impl<false>(y, l, D, tp);
+  }
+};
+
+// targets.h ThreeMixture1 (means equal in every coordinate but the first): the shared part over d >= 1 on the lane's own
+// range, combined canonically; the three first-coordinate terms from lane 0's y[0], broadcast through the quad.
+template <int W, int MIN_OWN>
+struct QThreeMixture1 {
+  static constexpr int kKind = PTRWM_TARGET_THREE_MIXTURE;
+  template <bool SCALED>
+  __device__ __forceinline__ static float impl(const float (&y)[W], const QLane &l, int D, const TParams &tp) {
+    const float *mu = tp.vec0 + l.d0;
+    [[maybe_unused]] const float *sc_v = SCALED ? tp.vec1 + l.d0 : nullptr;
+    float cl = 0.0f;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      if (l.d0 + j >= 1 && q_valid<MIN_OWN>(l, j)) {
+        float e;
+        if constexpr (SCALED) {
+          e = fmaf(y[j], sc_v[j], -mu[j]);
+        } else {
+          e = sub_rn(y[j], mu[j]);
+        }
+        cl = fmaf(e, e, cl);
+      }
+      if ((j & 7) == 7) sched_fence_soft();
+    }
+    const float c = quad_tree_add(cl);
+    const float y0 = quad_bcast<0>(y[0]);
+    const float *m0 = tp.vec0;  // wave-uniform addresses
+    float e0, e1, e2;
+    if constexpr (SCALED) {
+      const float sc = tp.vec1[0];
+      e0 = fmaf(y0, sc, -m0[0]), e1 = fmaf(y0, sc, -m0[D]), e2 = fmaf(y0, sc, -m0[2 * D]);
+    } else {
+      e0 = sub_rn(y0, m0[0]), e1 = sub_rn(y0, m0[D]), e2 = sub_rn(y0, m0[2 * D]);
+    }
+    return ThreeMixture<W>::finish(fmaf(e0, e0, c), fmaf(e1, e1, c), fmaf(e2, e2, c), tp);
   }
   __device__ __forceinline__ static float logp(const float (&y)[W], const QLane &l, int D, const TParams &tp) {
     return tp.vec1 != nullptr ? impl<true>(y, l, D, tp) : impl<false>(y, l, D, tp);
@@ -512,12 +559,12 @@ struct QNealFunnel {
 // machinery (log-density, swap uniform, outcome; three spare) -> (W + 2) floats per thread
 constexpr unsigned quad_kernel_lds_bytes(int threads, int w) { return (unsigned)(threads * (w + 2)) * 4u; }
 // Widest workgroup = one ladder.  Every variant is compiled for workgroups of up to 512 threads (ladders of <= 128
-// temperatures: up to 256 VGPRs, no spills); the W = 28 class (dim > 64), where this is the ONLY form of the fused kernel,
-// is also compiled for 1024 threads (ladders of <= 256 temperatures: 128 VGPRs, a dozen of them spilled).
+// temperatures: up to 256 VGPRs, no spills); the W >= 20 classes (dim > 64), where this is the ONLY form of the fused kernel,
+// are also compiled for 1024 threads (ladders of <= 256 temperatures: 128 VGPRs, a dozen of them spilled).
 constexpr int kQuadThreads = 512;
 constexpr int kQuadThreadsMax = 1024;
 
-// W      lane register width = canonical range width (8 / 16 / 28)
+// W      lane register width = canonical range width (8 / 16 / 20 / 24 / 28)
 // DEXACT dim compiled in (0: run-time dim, any value the width class covers)
 // MAXT   largest workgroup the variant may be launched with (kQuadThreads or kQuadThreadsMax)
 template <class Target, class Proposal, int W, int DEXACT, int MAXT, bool FULL>

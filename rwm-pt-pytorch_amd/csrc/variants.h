@@ -21,7 +21,9 @@ namespace ptrwm {
 #define PTRWM_WIDTHS_NARROW(X) \
   X(2, true) X(3, true) X(4, true) X(5, true) X(10, true) X(20, true) X(30, true) X(50, true) \
   X(8, false) X(16, false) X(24, false) X(32, false) X(40, false) X(48, false) X(56, false) X(64, false)
-#define PTRWM_WIDTHS_WIDE(X) X(100, true) X(80, false) X(104, false)
+// (one generic width per canonical class above 64 - 80 / 96 / 104 for W = 20 / 24 / 28, philox.h canon_width - so that the
+// register width a dim maps to always has the dim's own canonical range width)
+#define PTRWM_WIDTHS_WIDE(X) X(100, true) X(80, false) X(96, false) X(104, false)
 #define PTRWM_WIDTHS(X) PTRWM_WIDTHS_NARROW(X) PTRWM_WIDTHS_WIDE(X)
 
 // The max-ILP group must stay at register widths <= 64 (at most 232 VGPRs measured): a wider entry belongs in
@@ -29,7 +31,8 @@ namespace ptrwm {
 #define PTRWM_X_NARROW_OK(W, E) static_assert(W <= 64, "register widths above 64 belong in PTRWM_WIDTHS_WIDE (default scheduler)");
 PTRWM_WIDTHS_NARROW(PTRWM_X_NARROW_OK)
 #undef PTRWM_X_NARROW_OK
-#define PTRWM_X_WIDE_OK(W, E) static_assert(W > 64 && W <= PTRWM_MAX_DIM, "PTRWM_WIDTHS_WIDE holds the widths 65..PTRWM_MAX_DIM");
+#define PTRWM_X_WIDE_OK(W, E) static_assert(W > 64 && W <= PTRWM_MAX_DIM && (E || W == 4 * canon_width(W) || W == PTRWM_MAX_DIM), \
+                                            "PTRWM_WIDTHS_WIDE: widths 65..PTRWM_MAX_DIM, generic ones at the top of a canonical class");
 PTRWM_WIDTHS_WIDE(PTRWM_X_WIDE_OK)
 #undef PTRWM_X_WIDE_OK
 
@@ -109,13 +112,14 @@ hipError_t launch_logp(const float *x, float *out, long long n, int D, const TPa
 }
 
 // ---- lane-split ("quad") variants (quad.h): X(lane width W, dim compiled in or 0 for a run-time dim, max threads) ----
-// W is the canonical range width of the dim class (8 / 16 / 28 for dim <= 32 / 64 / 112); the BASELINE dims get a
-// kernel with dim compiled in, every other dim runs the generic kernel of its class.  The W = 28 class (dim > 64) is the
-// only form of the fused kernel there (see PTRWM_WIDTHS_WIDE above) and therefore also exists for 1024-thread workgroups
+// W is the canonical range width of the dim class (8 / 16 / 20 / 24 / 28 for dim <= 32 / 64 / 80 / 96 / 112); the BASELINE
+// dims get a kernel with dim compiled in, every other dim runs the generic kernel of its class.  The classes above dim 64
+// (W = 20, 24, 28) are the only form of the fused kernel there (see PTRWM_WIDTHS_WIDE above) and therefore also exists for 1024-thread workgroups
 // (ladders of 129..256 temperatures).
 #define PTRWM_QUAD_WIDTHS(X)                                                                              \
   X(8, 0, kQuadThreads) X(8, 20, kQuadThreads) X(8, 30, kQuadThreads) X(16, 0, kQuadThreads) X(16, 50, kQuadThreads) \
-  X(28, 0, kQuadThreads) X(28, 100, kQuadThreads) X(28, 0, kQuadThreadsMax) X(28, 100, kQuadThreadsMax)
+  X(20, 0, kQuadThreads) X(24, 0, kQuadThreads) X(28, 0, kQuadThreads) X(28, 100, kQuadThreads)                  \
+  X(20, 0, kQuadThreadsMax) X(24, 0, kQuadThreadsMax) X(28, 0, kQuadThreadsMax) X(28, 100, kQuadThreadsMax)
 struct QuadWidthInfo {
   int w, dexact, max_threads;
 };
@@ -259,6 +263,7 @@ hipError_t launch_run_quad(const KArgs &a, unsigned grid, bool full, hipStream_t
 PTRWM_DECLARE_TARGET_VARIANTS(rough_carpet_variants)
 PTRWM_DECLARE_TARGET_VARIANTS(rough_carpet2_variants)  // two-term specialisation, see targets.h
 PTRWM_DECLARE_TARGET_VARIANTS(three_mixture_variants)
+PTRWM_DECLARE_TARGET_VARIANTS(three_mixture1_variants)  // means differing in the first coordinate only, see targets.h
 PTRWM_DECLARE_TARGET_VARIANTS(full_rosenbrock_variants)
 PTRWM_DECLARE_TARGET_VARIANTS(even_rosenbrock_variants)
 PTRWM_DECLARE_TARGET_VARIANTS(hybrid_rosenbrock_variants)

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PTRWM_LIB: alternative build of the same library (A/B tuning experiments)
 LIB_PATH = os.environ.get("PTRWM_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libptrwm_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_DIM = 104
 MAX_TEMPS = 256
 
@@ -121,6 +121,7 @@ SYMBOLS = {
     "ptrwm_has_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "ptrwm_set_kernel_form": (C.c_int32, [C.c_int32]),
     "ptrwm_has_quad_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "ptrwm_has_thread_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "ptrwm_run": (C.c_int32, [C.POINTER(TargetDesc), C.POINTER(ProposalDesc), C.POINTER(RunArgs), C.c_void_p]),
     "ptrwm_swap_sweep": (C.c_int32, [C.POINTER(RunArgs), C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "ptrwm_split_propose": (
@@ -154,12 +155,15 @@ def load_library(path: Optional[str] = None):
             "There is no CPU fallback."
         )
     lib = C.CDLL(p)
+    # the version first: a library of another ABI version may lack symbols this binding types below
+    lib.ptrwm_abi_version.restype, lib.ptrwm_abi_version.argtypes = SYMBOLS["ptrwm_abi_version"]
+    if lib.ptrwm_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"ABI mismatch: library {p} is version {lib.ptrwm_abi_version()}, this binding {ABI_VERSION} "
+                           "(rebuild: make -C rwm-pt-pytorch_amd/csrc)")
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.ptrwm_abi_version() != ABI_VERSION:
-        raise RuntimeError(f"ABI mismatch: library {lib.ptrwm_abi_version()} vs binding {ABI_VERSION}")
     form = os.environ.get("PTRWM_KERNEL_FORM")  # tuning aid: auto | thread | quad (results are identical)
     if form:
         lib.ptrwm_set_kernel_form({"auto": FORM_AUTO, "thread": FORM_THREAD, "quad": FORM_QUAD}[form.lower()])
@@ -273,6 +277,11 @@ def has_variant(target_kind: int, proposal_kind: int, dim: int) -> bool:
 
 def has_quad_variant(target_kind: int, proposal_kind: int, dim: int, n_temps: int) -> bool:
     return bool(load_library().ptrwm_has_quad_variant(target_kind, proposal_kind, dim, n_temps))
+
+
+def has_thread_variant(target_kind: int, proposal_kind: int, dim: int) -> bool:
+    """Is there a one-thread-per-replica step kernel for this shape (never above dim 64)?"""
+    return bool(load_library().ptrwm_has_thread_variant(target_kind, proposal_kind, dim))
 
 
 def set_kernel_form(form: int) -> int:

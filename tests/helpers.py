@@ -86,7 +86,10 @@ def spec_from_params(cls: str, dim: int, params: dict) -> TargetSpec:
             c = (lnc + f32(np.sum(np.log(sf), dtype=f32))) + lw
         else:
             c = lnc + lw
-        return TargetSpec(kind, dim, tuple(c.astype(f32)), (), g("means").reshape(-1), sf, cls, params)
+        # ip[0] = 1 (include/ptrwm.h): means that differ in the first coordinate only -> the engine's ThreeMixture1 functor
+        m = g("means").reshape(3, dim)
+        first_only = bool(np.array_equal(m[0, 1:], m[1, 1:]) and np.array_equal(m[1, 1:], m[2, 1:]))
+        return TargetSpec(kind, dim, tuple(c.astype(f32)), (1 if first_only else 0,), m.reshape(-1), sf, cls, params)
     if kind in (O.TARGET_FULL_ROSENBROCK, O.TARGET_EVEN_ROSENBROCK):
         return TargetSpec(kind, dim, (g("a_coeff"), g("b_coeff")), (), g("mu"), None, cls, params)
     if kind == O.TARGET_HYBRID_ROSENBROCK:
@@ -548,26 +551,46 @@ def check_parity_philox(run, spec, prop, *, state, logp, beta, n_steps, burn_in,
     return flips
 
 
-def check_production_ladders(device, spec, prop, produced, *, state, beta, n_steps, burn_in, swap_every, seed,
-                             chain_offset=0, swap_mode=O.SWAP_EXCHANGE, swap_order=O.ORDER_SEQUENTIAL, segment=30):
-    """The first ladders of a PRODUCTION run (the non-fixture kernel variant, no trace, whatever kernel form the batch size
-    selected) tied to the oracle without any agreement-rate threshold, in two links:
+def spec_from_engine(target) -> TargetSpec:
+    """The TargetSpec of a ptrwm_hip.Target (device tensors copied to the host): the oracle then sees exactly the parameter
+    bits the kernel was given (a sampler class may fold its parameters with torch ops that differ from numpy's by an ulp)."""
+    host = lambda t: None if t is None else t.detach().cpu().numpy().astype(f32)  # noqa: E731
+    return TargetSpec(target.kind, target.dim, tuple(float(v) for v in target.p), tuple(int(v) for v in target.ip),
+                      host(target.vec0), host(target.vec1))
+
+
+def prop_from_engine(proposal) -> ProposalSpec:
+    host = lambda t: None if t is None else t.detach().cpu().numpy().astype(f32)  # noqa: E731
+    return ProposalSpec(proposal.kind, host(proposal.temp_scale), host(proposal.dim_scale), float(proposal.inv_dim))
+
+
+def check_production_run(run, x0, n_cmp, segment=50):
+    """The first `n_cmp` ladders of a finished PRODUCTION run of a sampler class (`run`: its algorithms._engine_core
+    EngineRun - the non-fixture kernel variant, no per-step trace, whatever kernel form the batch size selected) tied to
+    the oracle without any agreement-rate threshold, in two links:
       1. the fixture variant of the same kernel, run on the same Philox stream over just these ladders with a per-step
          trace and accept flags attached, reproduces the production run's final states, log-densities and all four
-         statistics BIT FOR BIT (`produced`: dict of the production run's arrays for these ladders);
+         statistics BIT FOR BIT;
       2. that traced run follows the oracle decision for decision over the full horizon, every differing decision
          proven (check_parity_philox).
-    state: the common starting point [n, T, D]; the starting log-densities are the engine's own (ptrwm_logdensity, the
-    call the sampler classes make), so both runs start from the same bits."""
+    Target and proposal parameters are read back from the run itself; x0 [dim]: the common starting point (every replica
+    and temperature starts there); the starting log-densities are the engine's own (ptrwm_logdensity, the call the classes
+    make), so both runs start from the same bits."""
     import ptrwm_hip as E
 
-    state = np.ascontiguousarray(state, dtype=f32)
-    logp = E.logdensity(spec.engine(device), dev_t(state.reshape(-1, state.shape[2]), device)).cpu().numpy().reshape(state.shape[:2])
-    kw = dict(state=state, logp=logp, beta=np.asarray(beta, f32), n_steps=n_steps, burn_in=burn_in, swap_every=swap_every,
-              swap_mode=swap_mode, swap_order=swap_order, chain_offset=chain_offset)
-    full = gpu_runner(spec, prop, device)(step0=0, seed=seed, **kw)
+    assert run.density_fn is None and run.manual_sweeps == 0
+    device = run.device
+    spec, prop = spec_from_engine(run.target), prop_from_engine(run.proposal)
+    T, D = run.n_temps, run.dim
+    state = np.broadcast_to(np.asarray(x0, f32), (n_cmp, T, D)).copy()
+    logp = E.logdensity(run.target, dev_t(state.reshape(-1, D), device)).cpu().numpy().reshape(n_cmp, T)
+    kw = dict(state=state, logp=logp, beta=run.beta.cpu().numpy(), n_steps=run.steps_done, burn_in=run.burn_in,
+              swap_every=run.swap_every, swap_mode=run.swap_mode, swap_order=run.swap_order, chain_offset=run.chain_offset)
+    full = gpu_runner(spec, prop, device)(step0=0, seed=run.seed, **kw)
+    produced = {"state": run.state, "logp": run.logp, "n_accept": run.n_accept, "sq_jump": run.sq_jump,
+                "swap_accept": run.swap_accept, "last_swap_ordinal": run.last_ord}
     for k, v in produced.items():
-        v = np.asarray(v)
+        v = v[:n_cmp].cpu().numpy()
         assert v.shape == full[k].shape and np.array_equal(v.view(np.uint8), np.ascontiguousarray(full[k]).view(np.uint8)), \
             f"production run and its traced fixture twin differ in `{k}`"
-    return check_parity_philox(gpu_runner(spec, prop, device), spec, prop, seed=seed, segment=segment, **kw)
+    return check_parity_philox(gpu_runner(spec, prop, device), spec, prop, seed=run.seed, segment=segment, **kw)

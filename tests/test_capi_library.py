@@ -91,6 +91,9 @@ def test_validation_needs_no_gpu(engine):
         for p in range(3):
             assert all(engine.has_quad_variant(t, p, d, n) for d in (1, 30, 32, 33, 50, 64, 65, 100, 104) for n in (1, 16, 17, 128))
             assert not engine.has_quad_variant(t, p, 30, 129) and not engine.has_quad_variant(t, p, 105, 4)
+            # one-thread-per-replica step kernels exist up to dim 64 only
+            assert all(engine.has_thread_variant(t, p, d) for d in (1, 30, 50, 64))
+            assert not any(engine.has_thread_variant(t, p, d) for d in (0, 65, 80, 100, 104, 105))
     # the kernel-form switch: returns the previous setting, rejects unknown values
     assert engine.set_kernel_form(engine.FORM_QUAD) == engine.FORM_AUTO
     assert engine.set_kernel_form(engine.FORM_AUTO) == engine.FORM_QUAD

@@ -147,11 +147,7 @@ def test_rwm_matches_oracle_statistics_many_chains(device):
     assert g_sq.sum() / want["sq_jump"].sum() == pytest.approx(1.0, rel=1e-3)
     # the first 256 chains decision for decision: the production run == its traced fixture twin bit for bit, and that
     # twin follows the oracle over the full horizon with every differing decision proven
-    n_prove = 256
-    produced = {"state": run.state[:n_prove].cpu().numpy(), "logp": run.logp[:n_prove].cpu().numpy(),
-                "n_accept": run.n_accept[:n_prove].cpu().numpy(), "sq_jump": run.sq_jump[:n_prove].cpu().numpy()}
-    H.check_production_ladders(device, spec, prop, produced, state=st[:n_prove], beta=[1.0],
-                               n_steps=N + burn, burn_in=burn, swap_every=1, seed=seed)
+    H.check_production_run(run, np.zeros(dim, np.float32), 256)
     # whole-population acceptance is consistent with the sample (binomial CI)
     p_all = alg.acceptance_rate
     p_s = want["n_accept"].sum() / (n_cmp * N)
@@ -453,12 +449,7 @@ def test_baseline_config3_properties(device):
     assert g_acc.sum() / want["n_accept"].sum() == pytest.approx(1.0, rel=2e-3)
     assert a._run.swap_accept[:n_cmp].sum().item() / want["swap_accept"].sum() == pytest.approx(1.0, rel=5e-3)
     # ... and decision for decision: production run == traced fixture twin (bit for bit) -> oracle (every flip proven)
-    r = a._run
-    produced = {"state": r.state[:n_cmp].cpu().numpy(), "logp": r.logp[:n_cmp].cpu().numpy(),
-                "n_accept": r.n_accept[:n_cmp].cpu().numpy(), "sq_jump": r.sq_jump[:n_cmp].cpu().numpy(),
-                "swap_accept": r.swap_accept[:n_cmp].cpu().numpy(), "last_swap_ordinal": r.last_ord[:n_cmp].cpu().numpy()}
-    H.check_production_ladders(device, spec, prop, produced, state=st, beta=ladder, n_steps=100, burn_in=20,
-                               swap_every=10, seed=4242)
+    H.check_production_run(a._run, np.zeros(dim, np.float32), n_cmp)
     # even/odd: half the pairs per event
     e = make("even_odd")
     e.generate_samples(80)
@@ -526,12 +517,7 @@ def test_baseline_config4_and_5_shard_properties(device, cfg):
     g_acc = a._run.n_accept[:n_cmp].cpu().numpy()
     assert g_acc.sum() / want["n_accept"].sum() == pytest.approx(1.0, rel=3e-3)
     # ... and decision for decision: production run == traced fixture twin (bit for bit) -> oracle (every flip proven)
-    r = a._run
-    produced = {"state": r.state[:n_cmp].cpu().numpy(), "logp": r.logp[:n_cmp].cpu().numpy(),
-                "n_accept": r.n_accept[:n_cmp].cpu().numpy(), "sq_jump": r.sq_jump[:n_cmp].cpu().numpy(),
-                "swap_accept": r.swap_accept[:n_cmp].cpu().numpy(), "last_swap_ordinal": r.last_ord[:n_cmp].cpu().numpy()}
-    H.check_production_ladders(device, spec, pspec, produced, state=st, beta=ladder, n_steps=burn + n,
-                               burn_in=burn, swap_every=se, seed=777, chain_offset=offset)
+    H.check_production_run(a._run, x0, n_cmp)
     assert a._run.swap_accept[:n_cmp].sum().item() / max(1, want["swap_accept"].sum()) == pytest.approx(1.0, rel=1e-2)
     # whole-job summary at world size 1 == the local summary
     local = a._run.summary()

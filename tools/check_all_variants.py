@@ -29,6 +29,12 @@ def make_spec(H, kind, dim, rng):
         return H.spec_from_params("RoughCarpetDistributionTorch", dim, {"modes": f32([-4, 0, 4]), "weights": f32([0.2, 0.5, 0.3])}), np.zeros(dim)
     if kind == 10:  # RoughCarpet2 kernels (well-separated modes)
         return H.spec_from_params("RoughCarpetDistributionTorch", dim, {"modes": f32([-15, 0, 15]), "weights": f32([0.5, 0.3, 0.2])}), np.zeros(dim)
+    if kind == 11:  # ThreeMixture1 kernels (means differing in the first coordinate only: spec_from_params sets ip[0] = 1)
+        means = np.tile(rng.normal(0, 2, (1, dim)).astype(f32), (3, 1))
+        means[:, 0] = f32([-4.0, 0.5, 5.0])
+        spec = H.spec_from_params("ThreeMixtureDistributionTorch", dim, {"means": means, "mixing_weights": f32([0.3, 0.3, 0.4])})
+        assert spec.ip[0] == 1
+        return spec, np.zeros(dim)
     if kind == 1:
         return H.spec_from_params("ThreeMixtureDistributionTorch", dim, {"means": rng.normal(0, 2, (3, dim)).astype(f32),
                                                                           "mixing_weights": f32([0.3, 0.3, 0.4])}), np.zeros(dim)
@@ -171,7 +177,7 @@ if __name__ == "__main__":
     if len(sys.argv) == 3:
         sys.exit(1 if one_pair(int(sys.argv[1]), int(sys.argv[2])) else 0)
     failed = []
-    for tk in range(11):
+    for tk in range(12):
         for pk in range(3):
             r = subprocess.run([sys.executable, os.path.abspath(__file__), str(tk), str(pk)], capture_output=True, text=True, timeout=600)
             tail = [l for l in r.stdout.splitlines() if l.strip()][-3:]

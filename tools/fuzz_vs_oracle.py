@@ -25,7 +25,7 @@ f32 = np.float32
 
 
 def random_target(rng, dim):
-    fam = rng.choice(["rc", "rc_scaled", "tm", "full", "even", "hyb", "gamma", "beta", "mvn", "smvn", "cube", "funnel"])
+    fam = rng.choice(["rc", "rc_scaled", "tm", "tm_first", "full", "even", "hyb", "gamma", "beta", "mvn", "smvn", "cube", "funnel"])
     if fam in ("rc", "rc_scaled"):
         m = np.sort(rng.uniform(-12, 12, 3)).astype(f32)
         w = rng.dirichlet([2, 2, 2]).astype(f32)
@@ -33,8 +33,14 @@ def random_target(rng, dim):
         if fam == "rc_scaled":
             params["scaling_factors"] = rng.uniform(0.5, 1.5, dim).astype(f32)
         return H.spec_from_params("RoughCarpetDistributionTorch", dim, params), np.zeros(dim)
-    if fam == "tm":
+    if fam in ("tm", "tm_first"):
         means = rng.normal(0, 3, (3, dim)).astype(f32)
+        if fam == "tm_first":  # the three means differ in the first coordinate only: the ThreeMixture1 kernels (ip[0] = 1)
+            means[1:, 1:] = means[0, 1:]
+        if rng.random() < 0.3:
+            return H.spec_from_params("ThreeMixtureDistributionTorch", dim,
+                                      {"means": means, "mixing_weights": rng.dirichlet([2, 2, 2]).astype(f32),
+                                       "scaling_factors": rng.uniform(0.5, 1.5, dim).astype(f32)}), np.zeros(dim)
         return H.spec_from_params("ThreeMixtureDistributionTorch", dim,
                                   {"means": means, "mixing_weights": rng.dirichlet([2, 2, 2]).astype(f32)}), np.zeros(dim)
     if fam in ("full", "even"):

@@ -2,7 +2,7 @@
 (rwm-pt-pytorch_amd/build/*.o: .hip_fatbin -> gfx950 code object -> NT_AMDGPU_METADATA), no recompilation.
 
     python tools/kernel_stats.py [--objdir DIR] [filter-substring]     table of every kernel whose name contains the filter
-    python tools/kernel_stats.py --check [--objdir DIR]                the build gate run by csrc/Makefile
+    python tools/kernel_stats.py --check [--objdir DIR | --objs a.o b.o ...]   the build gate run by csrc/Makefile
 
 --check fails (exit 1) if ANY kernel needs more than 256 VGPRs or any AGPR.  That is the regime (AGPR copies next to
 ~150-200 SGPRs spilled into VGPR lanes) in which hipcc produced wrong code for the one-thread-per-replica kernels of the
@@ -11,7 +11,11 @@ DEFAULT scheduler after a scheduling fence moved.  Those kernels are retired (di
 gate keeps any future kernel out of that regime.
 It also fails if a PRODUCTION step kernel (FULL = false) of the max-ILP group (variants_*.o) uses scratch memory
 (DESIGN.md 3.1 promises none; round 2 found and fixed 16 + 4 DP bytes per thread in every HybridRosenbrock kernel this
-way); scratch elsewhere (the 1024-thread lane-split variants of the dim > 64 class spill a dozen VGPRs) is reported."""
+way); scratch elsewhere (the 1024-thread lane-split variants of the dim > 64 class spill a dozen VGPRs) is reported;
+if a production step kernel spills more SGPRs than PROD_SGPR_SPILL_CEILING (a ratchet: each spilled SGPR is a
+v_writelane / v_readlane pair in the step loop, and heavy SGPR spilling next to the empty-asm value barriers is the other
+ingredient of the register regime above); and if an object yields NO kernel at all (a different ROCm layout, a stripped
+object: the gate must not pass without having looked at anything)."""
 import glob
 import os
 import re
@@ -21,6 +25,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
+PROD_SGPR_SPILL_CEILING = 163  # the maximum when the ratchet was introduced (round 3: HybridRosenbrock<64> + UniformRadius, thread form); lower it, never raise it
 FIELDS = ("agpr_count", "vgpr_count", "vgpr_spill_count", "sgpr_count", "sgpr_spill_count", "private_segment_fixed_size",
           "group_segment_fixed_size")
 
@@ -58,20 +63,37 @@ def main():
         i = args.index("--objdir")
         objdir = args[i + 1]
         del args[i:i + 2]
+    objs = None
+    if "--objs" in args:  # the Makefile's own object list: stale objects of retired variants in the directory are not looked at
+        i = args.index("--objs")
+        objs = args[i + 1:]
+        del args[i:]
     flt = args[0] if args else ""
-    objs = sorted(glob.glob(os.path.join(objdir, "*.o")))
+    if objs is None:
+        objs = sorted(glob.glob(os.path.join(objdir, "*.o")))
     if not objs:
         sys.exit(f"no objects under {objdir}: build first (make -C rwm-pt-pytorch_amd/csrc)")
     bad, notes = [], []
-    n = 0
+    n = n_step = 0
+    worst_spill = (0, "")
     for obj in objs:
         base = os.path.basename(obj)
         maxilp = base.startswith("variants_") and not base.endswith(".wide.o")
-        for name, m in kernels_of(obj):
+        found = kernels_of(obj)
+        if check and not found:
+            bad.append(f"{base}: no gfx950 kernel metadata found (llvm-objcopy / clang-offload-bundler / llvm-readelf under "
+                       f"{LLVM} could not read it): the gate has nothing to check")
+        for name, m in found:
             n += 1
             is_step = "step_kernel" in name
             production = is_step and re.search(r"ELb[01]ELb0E+vNS_5KArgsE$", name) is not None
+            n_step += is_step
+            if production and m["sgpr_spill_count"] > worst_spill[0]:
+                worst_spill = (m["sgpr_spill_count"], f"{base}: {short(name)}")
             if check:
+                if production and m["sgpr_spill_count"] > PROD_SGPR_SPILL_CEILING:
+                    bad.append(f"{base}: production kernel {short(name)} spills {m['sgpr_spill_count']} SGPRs "
+                               f"(ceiling {PROD_SGPR_SPILL_CEILING})")
                 if m["vgpr_count"] > 256 or m["agpr_count"] > 0:
                     bad.append(f"{base}: {short(name)} needs vgpr_count {m['vgpr_count']}, agpr_count {m['agpr_count']} "
                                "(limit 256 / 0): the register regime hipcc miscompiled twice")
@@ -88,8 +110,9 @@ def main():
         if bad:
             print("\n".join(bad))
             sys.exit(f"kernel_stats --check: {len(bad)} violation(s) in {n} kernels")
-        print(f"kernel_stats --check: {n} kernels in {len(objs)} objects ok (every kernel <= 256 VGPRs and no AGPRs; "
-              "production step kernels of the max-ILP group: no scratch)")
+        print(f"kernel_stats --check: {n} kernels ({n_step} step kernels) in {len(objs)} objects ok (every kernel <= 256 VGPRs "
+              f"and no AGPRs; production step kernels: no scratch in the max-ILP group, at most {worst_spill[0]} spilled "
+              f"SGPRs [{worst_spill[1]}], ceiling {PROD_SGPR_SPILL_CEILING})")
 
 
 if __name__ == "__main__":
