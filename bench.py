@@ -160,7 +160,10 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    # under torch.distributed.run (RANK / WORLD_SIZE in the environment) the process group is created whatever the world
+    # size: a one-rank launch then exercises the same init / barrier / all-reduce / destroy sequence as the 8-GPU one
+    distributed = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -211,7 +214,7 @@ def main():
     run = alg._run
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -228,7 +231,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -408,6 +411,7 @@ def main():
                 "dim": dim, "temps": T, "ladders_per_gpu": C, "mh_steps_per_launch": args.inner,
                 "swap_every": args.swap_every, "swap_mode": "exchange", "swap_order": args.swap_order,
                 "rng": "Philox4x32-10 in-kernel", "sharding": f"{world} x {C} independent ladders, no data-path collective",
+                "collective_backend": (backend if distributed else None),
             },
             "roofline": roof,
             "summary": {
@@ -423,7 +427,7 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

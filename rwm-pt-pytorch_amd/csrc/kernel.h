@@ -165,31 +165,56 @@ __device__ __forceinline__ void swap_decide(int T, int t, int base, int slot, in
   }
 }
 
-// dst[i] = src[i] for i = tid, tid + nthr, ... < total with sixteen independent loads in flight per thread: full
-// chunks unpredicated, then one predicated chunk for the remainder.  (A plain loop waits for every load before
-// issuing the next one when the stride is a run-time value: 1.7x slower for the one-step-per-launch case.)
-__device__ __forceinline__ void stage_copy(float *__restrict__ dst, const float *__restrict__ src, int total, int tid,
-                                           int nthr) {
-  constexpr int kDepth = 16;
-  int i0 = tid;
-  for (; i0 + (kDepth - 1) * nthr < total; i0 += kDepth * nthr) {
-    float v[kDepth];
+// Staging between a group's contiguous run of `total` floats in HBM (`g`, any 4-byte alignment) and its LDS slab, 16 bytes
+// per lane per instruction (global_load_dwordx4 / ds_write_b128 and the reverse).  Element i of the run lives at
+// lds[stage_head(g) + i], stage_head = the run's first float index modulo 4: an aligned 16-byte vector of HBM is then an
+// aligned 16-byte vector of the slab (slabs start 256-byte aligned), so whole vectors move as vectors; the <= 3 elements
+// before the first and after the last whole vector are moved one by one.  The slab needs room for total + 3 floats: the
+// rows fill it exactly when every slot is live and dim equals the register width, and the overhang then lands in the
+// swap scratch behind the rows, which is dead while a copy runs.
+// Four independent vectors in flight per lane: full chunks unpredicated, then one predicated chunk.  (A plain loop waits
+// for every load before issuing the next one when the stride is a run-time value: 1.7x slower for one step per launch.)
+__device__ __forceinline__ int stage_head(const float *g) { return (int)((reinterpret_cast<uintptr_t>(g) >> 2) & 3u); }
+
+template <bool LOAD>  // LOAD: HBM -> LDS, else LDS -> HBM
+__device__ __forceinline__ void stage_copy(float *__restrict__ lds, float *__restrict__ g, int total, int tid, int nthr) {
+  typedef float vec4 __attribute__((ext_vector_type(4)));
+  const int head = stage_head(g);
+  vec4 *__restrict__ gv = reinterpret_cast<vec4 *>(g - head);  // the aligned frame; vector 0 is touched only if head == 0
+  vec4 *__restrict__ lv = reinterpret_cast<vec4 *>(lds);
+  const int v_lo = head ? 1 : 0;          // first whole vector
+  const int v_hi = (head + total) >> 2;   // one past the last whole vector
+  constexpr int kDepth = 4;
+  int v0 = v_lo + tid;
+  for (; v0 + (kDepth - 1) * nthr < v_hi; v0 += kDepth * nthr) {
+    vec4 t[kDepth];
 #pragma unroll
-    for (int k = 0; k < kDepth; ++k) v[k] = src[i0 + k * nthr];
+    for (int k = 0; k < kDepth; ++k) t[k] = LOAD ? gv[v0 + k * nthr] : lv[v0 + k * nthr];
 #pragma unroll
-    for (int k = 0; k < kDepth; ++k) dst[i0 + k * nthr] = v[k];
+    for (int k = 0; k < kDepth; ++k) (LOAD ? lv : gv)[v0 + k * nthr] = t[k];
   }
-  if (i0 < total) {
-    float v[kDepth - 1];
+  if (v0 < v_hi) {
+    vec4 t[kDepth - 1];
 #pragma unroll
     for (int k = 0; k < kDepth - 1; ++k) {
-      const int i = i0 + k * nthr;
-      v[k] = i < total ? src[i] : 0.0f;
+      const int v = v0 + k * nthr;
+      if (v < v_hi) t[k] = LOAD ? gv[v] : lv[v];
     }
 #pragma unroll
     for (int k = 0; k < kDepth - 1; ++k) {
-      const int i = i0 + k * nthr;
-      if (i < total) dst[i] = v[k];
+      const int v = v0 + k * nthr;
+      if (v < v_hi) (LOAD ? lv : gv)[v] = t[k];
+    }
+  }
+  // the ragged ends: elements [0, e_lo) before the first whole vector and [e_hi, total) after the last one
+  const int e_lo = (4 * v_lo - head < total) ? 4 * v_lo - head : total;
+  const int e_hi = (4 * v_hi - head > e_lo) ? 4 * v_hi - head : e_lo;
+  if (tid < 6) {
+    const int i = tid < 3 ? tid : e_hi + (tid - 3);
+    const bool mine = tid < 3 ? (i < e_lo) : (i < total);
+    if (mine) {
+      if (LOAD) lds[head + i] = g[i];
+      else g[i] = lds[head + i];
     }
   }
 }
@@ -277,11 +302,11 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
   {
     const long long live_chains = (a.n_chains - chain0 < cpw) ? (a.n_chains - chain0) : cpw;
     const int stage_total = (int)live_chains * T * D0;  // floats of this group's run
-    const float *__restrict__ gs = a.state + chain0 * T * (long long)D0;
+    float *__restrict__ gs = a.state + chain0 * T * (long long)D0;
     const int nthr = wide ? ((T + 63) & ~63) : 64;  // threads of the group = of the workgroup
-    stage_copy(s_stage, gs, stage_total, tid, nthr);
+    stage_copy<true>(s_stage, gs, stage_total, tid, nthr);
     sync_group();
-    const float *row = s_stage + (live ? tid : 0) * D0;  // idle threads shadow row 0 = replica (chain0, 0)
+    const float *row = s_stage + stage_head(gs) + (live ? tid : 0) * D0;  // idle threads shadow row 0 = replica (chain0, 0)
 #pragma unroll
     for (int d = 0; d < DP; ++d) x[d] = (d < D0) ? row[d] : 0.0f;
   }
@@ -470,17 +495,17 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     const int stage_total = (int)live_chains * T2 * D2;
     const long long stage_g0 = c0 * T2 * (long long)D2;
     c0_out = c0;
+    float *__restrict__ gs = a.state + stage_g0;
     sync_group();  // the last swap's row reads are done before the rows are overwritten
     if (live) {
-      float *row = rows2 + tid2 * D2;
+      float *row = rows2 + stage_head(gs) + tid2 * D2;
 #pragma unroll
       for (int d = 0; d < DP; ++d)
         if (d < D2) row[d] = x[d];
     }
     sync_group();
-    float *__restrict__ gs = a.state + stage_g0;
     const int nthr = wide2 ? ((T2 + 63) & ~63) : 64;
-    stage_copy(gs, rows2, stage_total, tid2, nthr);
+    stage_copy<false>(rows2, gs, stage_total, tid2, nthr);
   }
   if (live) {
     const int tid_o = opaque_vgpr((int)threadIdx.x);
@@ -493,9 +518,11 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     const unsigned n_swap_acc = (unsigned)park[gt_o];
     const int last_event = park[2 * gt_o];
     a.logp[rep] = lp;
-    if (a.n_accept != nullptr) a.n_accept[rep] += (long long)n_acc;
-    if (a.sq_jump != nullptr) a.sq_jump[rep] += sq;
-    if (a.swap_accept != nullptr) a.swap_accept[rep] += (long long)n_swap_acc;
+    // statistics: read-modify-write only where this launch has something to add (a launch without a swap event - nine in
+    // ten at one step per launch - then leaves the swap counters' cache lines alone)
+    if (a.n_accept != nullptr && n_acc != 0u) a.n_accept[rep] += (long long)n_acc;
+    if (a.sq_jump != nullptr && sq != 0.0) a.sq_jump[rep] += sq;
+    if (a.swap_accept != nullptr && n_swap_acc != 0u) a.swap_accept[rep] += (long long)n_swap_acc;
     if (a.last_swap_ordinal != nullptr && last_event >= 0) {
       // 1-based attempt ordinal counted from the start of the run.  Sequential order: T-1 attempts
       // per event; even/odd events have a varying pair count, so the event number is recorded.

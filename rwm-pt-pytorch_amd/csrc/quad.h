@@ -618,9 +618,10 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
   {
     const long long live_chains = (a.n_chains - chain0 < cpw) ? (a.n_chains - chain0) : cpw;
     const int stage_total = (int)live_chains * T * D;
-    stage_copy(rows, a.state + chain0 * T * (long long)D, stage_total, tid, gthreads);
+    float *__restrict__ gs = a.state + chain0 * T * (long long)D;
+    stage_copy<true>(rows, gs, stage_total, tid, gthreads);
     sync_group();
-    const float *seg = rows + slot * D + l.d0;
+    const float *seg = rows + stage_head(gs) + slot * D + l.d0;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
       x[j] = q_valid<MIN_OWN>(l, j) ? seg[j] : 0.0f;
@@ -797,21 +798,22 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
   {
     const long long live_chains = (a.n_chains - chain0 < cpw) ? (a.n_chains - chain0) : cpw;
     const int stage_total = (int)live_chains * T * D;
+    float *__restrict__ gs = a.state + chain0 * T * (long long)D;
     sync_group();  // the last swap's row reads are done before the rows are overwritten
     if (live) {
-      float *seg = rows + slot * D + l.d0;
+      float *seg = rows + stage_head(gs) + slot * D + l.d0;
 #pragma unroll
       for (int j = 0; j < W; ++j)
         if (q_valid<MIN_OWN>(l, j)) seg[j] = x[j];
     }
     sync_group();
-    stage_copy(a.state + chain0 * T * (long long)D, rows, stage_total, tid, gthreads);
+    stage_copy<false>(rows, gs, stage_total, tid, gthreads);
   }
   if (live && l.q == 0) {
     a.logp[rep] = lp;
-    if (a.n_accept != nullptr) a.n_accept[rep] += (long long)n_acc;
-    if (a.sq_jump != nullptr) a.sq_jump[rep] += sq;
-    if (a.swap_accept != nullptr) a.swap_accept[rep] += (long long)n_swap_acc;
+    if (a.n_accept != nullptr && n_acc != 0u) a.n_accept[rep] += (long long)n_acc;  // (kernel.h: RMW only where there is a delta)
+    if (a.sq_jump != nullptr && sq != 0.0) a.sq_jump[rep] += sq;
+    if (a.swap_accept != nullptr && n_swap_acc != 0u) a.swap_accept[rep] += (long long)n_swap_acc;
     if (a.last_swap_ordinal != nullptr && last_event >= 0) {
       const long long ev = a.first_swap_event + last_event;
       const long long ord = (a.swap_order == PTRWM_ORDER_SEQUENTIAL) ? ev * (T - 1) + t + 1 : ev + 1;

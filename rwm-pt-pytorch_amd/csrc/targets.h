@@ -266,9 +266,15 @@ struct HybridRosenbrock {
     const float c0 = y[0] - mu;
     constexpr int W = canon_width(DP);
     float acc[4] = {a * c0 * c0, 0.0f, 0.0f, 0.0f};  // the x_0 term opens the chain of the first range
+    // the block-head bits, re-materialised per evaluation: tested in place (s_bitcmp1_b64 + s_cselect_b64 next to the
+    // v_cndmask that uses them).  Left loop-invariant, the compiler hoists one 64-bit lane mask PER DIMENSION out of the
+    // step loop - up to 128 SGPRs that live for the whole launch, i.e. in spill lanes (110-163 spilled SGPRs in these
+    // kernels before; tools/kernel_stats.py)
+    unsigned long long mask[2] = {tp.mask[0], tp.mask[1]};
+    asm volatile("" : "+s"(mask[0]), "+s"(mask[1]));
     PTRWM_DIM_LOOP(i, DP, D, {
       if (i >= 1) {
-        const bool head = (tp.mask[i >> 6] >> (i & 63)) & 1ull;
+        const bool head = (mask[i >> 6] >> (i & 63)) & 1ull;
         // select between the two VALUES: left alone the optimiser selects the INDEX (head ? 0 : i - 1), which makes
         // y[] dynamically indexed and moves the whole vector to scratch memory (16 + 4 DP bytes per thread, found by
         // tools/kernel_stats.py --check); the empty asm pins the second candidate in a register first

@@ -33,7 +33,27 @@ def rate(dim, T, C, form, target_steps=2e9):
     return C * T * inner * 3 / (e0.elapsed_time(e1) * 1e-3)
 
 
+def dense(held_out=False):
+    """The table the AUTO rule of csrc/capi.hip is fitted on (and, with held_out, the one it is checked against): both
+    pinned forms and AUTO over waves-per-SIMD of the thread form, ladder lengths and dims; one line per case."""
+    ws = (0.6, 0.9, 1.1, 1.4, 1.6, 1.9, 2.2, 2.75, 3.5) if held_out else (0.25, 0.5, 0.75, 1.0, 1.25, 1.5, 1.75, 2.0, 2.5, 3.0, 4.0)
+    dims = (24, 30, 44, 52, 60) if held_out else (20, 30, 41, 48, 57, 64)
+    print(f"{'dim':>4} {'T':>4} {'chains':>7} {'w':>5} {'thread':>10} {'quad':>10} {'auto':>10} {'auto/best':>9}")
+    worst = 1.0
+    for dim in dims:
+        for T in (1, 8, 32, 64):
+            cpw = 1 if T > 64 else 64 // T
+            for w in ws:
+                C = max(1, int(round(w * 1024 * cpw)))
+                a, b, c = rate(dim, T, C, E.FORM_THREAD, 1e9), rate(dim, T, C, E.FORM_QUAD, 1e9), rate(dim, T, C, E.FORM_AUTO, 1e9)
+                worst = min(worst, c / max(a, b))
+                print(f"{dim:4d} {T:4d} {C:7d} {w:5.2f} {a:10.3e} {b:10.3e} {c:10.3e} {c / max(a, b):9.3f}", flush=True)
+    print(f"# worst AUTO / best pinned form: {worst:.3f}")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] in ("dense", "heldout"):
+        return dense(sys.argv[1] == "heldout")
     cases = [(30, 1, c) for c in (1024, 8192, 32768, 65536, 81920, 98304, 131072, 262144)] + \
             [(30, 8, c) for c in (1, 64, 1024, 4096, 8192, 16384, 32768)] + \
             [(30, 32, c) for c in (1, 64, 1024, 2048, 3072, 4096, 8192)] + \
