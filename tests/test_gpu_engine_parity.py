@@ -427,6 +427,40 @@ def test_chain_offset_makes_sharding_invisible(device):
     assert np.array_equal(whole["n_accept"], np.concatenate([lo["n_accept"], hi["n_accept"]]))
 
 
+@pytest.mark.parametrize("form", ["thread", "quad"])
+@pytest.mark.parametrize("dim,T,Cn", [(7, 3, 100), (30, 32, 9), (5, 1, 333), (13, 70, 3), (81, 4, 21)])
+def test_state_alignment_is_invisible(device, dim, T, Cn, form):
+    """The kernels stage their group's run of the state through LDS in 16-byte vectors whatever the run's alignment
+    (kernel.h stage_copy: the vectors of the aligned frame, the ragged ends element by element): a state array that
+    starts 4, 8 or 12 bytes past a 16-byte boundary, with group runs of every alignment inside it, gives the bits of the
+    aligned one, and nothing outside the array is touched."""
+    params = {"modes": np.float32([-4, 0, 4]), "weights": np.float32([0.2, 0.5, 0.3])}
+    spec = H.spec_from_params("RoughCarpetDistributionTorch", dim, params)
+    if form == "thread" and not E.has_thread_variant(spec.kind, 0, dim):
+        pytest.skip("one form only above dim 64")
+    beta = (0.1 ** (np.arange(T) / max(1, T - 1))).astype(np.float32)
+    prop = H.proposal_spec("Normal", dim, beta, base_variance_scalar=2.38**2 / dim)
+    rng = np.random.default_rng(dim * T)
+    st = rng.normal(0, 3, (Cn, T, dim)).astype(np.float32)
+    lp = O.logdensity(spec.oracle(), st.reshape(-1, dim)).astype(np.float32).reshape(Cn, T)
+    kw = dict(beta=dev_t(beta, device), step0=0, n_steps=25, burn_in=2, swap_every=3, seed=5, chain_offset=11)
+    n = st.size
+    outs = []
+    with E.kernel_form({"thread": E.FORM_THREAD, "quad": E.FORM_QUAD}[form]):
+        for shift in (0, 1, 2, 3):
+            buf = torch.full((n + 8,), 7.25, device=device)
+            view = buf[shift:shift + n].view(Cn, T, dim)
+            view.copy_(dev_t(st, device))
+            lpd = dev_t(lp, device)
+            E.run(spec.engine(device), prop.engine(device), state=view, logp=lpd, **kw)
+            torch.cuda.synchronize()
+            assert bool((buf[:shift] == 7.25).all()) and bool((buf[shift + n:] == 7.25).all())
+            outs.append((view.cpu().numpy().copy(), lpd.cpu().numpy()))
+    for s_, l_ in outs[1:]:
+        assert np.array_equal(s_, outs[0][0]) and np.array_equal(l_, outs[0][1])
+    assert not np.array_equal(outs[0][0], st)
+
+
 def test_argument_validation_through_the_abi(device):
     spec = H.target_spec("rc15_d30")
     prop = H.proposal_spec("Normal", 30, [1.0], base_variance_scalar=0.1)

@@ -1,8 +1,12 @@
 mkdir -p gpurun_out
-for w in cfg5 cfg4 cfg2; do python bench.py --workload $w --cpu-seconds 0 --no-extras --steps 10 --warmup 3 > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err; python -c "
-import json; d=json.load(open('gpurun_out/bench_$w.json')); print('$w', '%.4g'%d['value'], d['roofline'].get('kernel_ms'), d['config']['workload'][:60])"; done
-python bench.py --cpu-seconds 0 --no-extras --steps 10 --warmup 3 > gpurun_out/bench_cfg3.json 2> gpurun_out/bench_cfg3.err; python -c "
-import json; d=json.load(open('gpurun_out/bench_cfg3.json')); print('cfg3', '%.4g'%d['value'], d['roofline'].get('kernel_ms'))"
 timeout -k 10 1000 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; rc=$?; echo pytest rc=$rc; grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/pytest_gpu.log | tail -20
 if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then exit $rc; fi
-timeout -k 10 900 python tools/check_all_variants.py > gpurun_out/check_all_variants.txt 2>&1; echo cav rc=$?; tail -5 gpurun_out/check_all_variants.txt
+python bench.py --cpu-seconds 0 > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err; python - <<'PY'
+import json
+d = json.load(open('gpurun_out/bench_full.json'))
+print('value %.4g' % d['value'], 'kernel_ms', d['roofline']['kernel_ms'])
+i1 = d['roofline']['hbm_stream_inner1']; print('inner1', i1['kernel_ms_mean'], i1['kernel_ms_median'], i1['frac'])
+for k, v in d['other_single_gpu_readings'].items(): print('%.4g' % v['value'], k[:70])
+PY
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 -L > /root/repo/gpurun_out/rocprof_counters.txt 2>&1); grep -c . gpurun_out/rocprof_counters.txt; grep -o "SQ_INSTS_VALU[A-Z0-9_]*" gpurun_out/rocprof_counters.txt | sort -u | tr '\n' ' '
+python tools/form_sweep.py dense > gpurun_out/r03_form_dense.txt 2>&1; tail -3 gpurun_out/r03_form_dense.txt

@@ -1,0 +1,203 @@
+"""Cost-weighted issue roofline of a fused step kernel: the opcode histogram of ONE Metropolis step of the kernel (the path
+through its step loop that a step without a swap event takes), each opcode weighted with its measured issue cost
+(tools/issue_cost.hip -> profiles/r03_issue_costs.json), against the SIMD time a wave-step really takes.
+
+    python tools/issue_model.py [--tu rough_carpet2] [--kernel <mangled-name filter>] [--costs profiles/r03_issue_costs.json]
+                                [--valu-per-wave-step N] [--salu-per-wave-step N] [--ns-per-wave-step X] [--json out.json]
+
+How the histogram is obtained (no GPU needed, ~1 min): the translation unit is compiled again with the Makefile's flags and
+-save-temps; the annotated assembly gives the basic blocks of the kernel and its step loop (the depth-1 loop holding the
+Philox multiplies).  A step WITHOUT a swap event executes one path from the loop header back to itself; that path is found by
+enumerating the simple paths of the loop's control-flow graph and taking the one that avoids LDS traffic, barriers, inner
+loops (all three are the swap event) and in-loop scalar loads of a NULL parameter vector (the `scaled` twin of the target):
+`s_cbranch_exec*` skips are not taken (the wave has live lanes).  The choice is CHECKED, not trusted: the path's VALU and SALU
+instruction counts must equal the SQ_INSTS_VALU / SQ_INSTS_SALU per wave-step that rocprofv3 counted for the same kernel run
+without swap events (bench.py --swap-every 1073741824, profiles/r03_pmc_cfg3_noswap.csv) when those are given.
+
+Output: per opcode count x cost, the sum = busy SIMD time per wave-step, and its ratio to the measured time per wave-step
+(kernel time x SIMDs / (waves x steps)) = the cost-weighted issue fraction.  Opcodes without a measured cost are priced
+as v_fma_f32 and listed."""
+import argparse
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCHED = "-mllvm -enable-post-misched=0 -mllvm -amdgpu-sched-strategy=max-ilp -fno-slp-vectorize".split()
+HEADLINE = "ptrwm_step_kernelINS_12RoughCarpetTILi30ELb1EEENS_14NormalProposalILi30EEELi30ELb1ELb0EEE"
+
+# opcode (as printed, VOP suffixes stripped) -> the measured opcode whose cost it shares
+ALIAS = {
+    "v_sub_f32": "v_add_f32", "v_subrev_f32": "v_add_f32", "v_max_f32": "v_add_f32", "v_min_f32": "v_add_f32",
+    "v_mov_b32": "v_add_f32", "v_and_b32": "v_xor_b32", "v_or_b32": "v_xor_b32", "v_lshlrev_b32": "v_lshrrev_b32",
+    "v_fmac_f32": "v_fma_f32", "v_fmaak_f32": "v_fmamk_f32", "v_min3_f32": "v_max3_f32", "v_sub_u32": "v_add_u32",
+    "v_subrev_u32": "v_add_u32", "v_add3_u32": "v_and_or_b32", "v_cmp_gt_f32": "v_cmp_lt_f32", "v_cmp_ge_f32": "v_cmp_lt_f32",
+    "v_cmp_le_f32": "v_cmp_lt_f32", "v_cmp_ngt_f32": "v_cmp_lt_f32", "v_cmp_nlt_f32": "v_cmp_lt_f32", "v_cmp_eq_u32": "v_cmp_lt_f32",
+    "v_cmp_ne_u32": "v_cmp_lt_f32", "v_cmp_lt_u32": "v_cmp_lt_f32", "v_cmp_gt_u32": "v_cmp_lt_f32", "v_cmp_lt_i32": "v_cmp_lt_f32",
+    "v_cmp_gt_i32": "v_cmp_lt_f32", "v_cmp_class_f32": "v_cmp_lt_f32", "v_cvt_f32_i32": "v_cvt_f32_u32", "v_mul_hi_u32": "v_mul_lo_u32",
+    "v_mul_f64": "v_fma_f64", "v_accvgpr_read_b32": "v_add_f32", "v_accvgpr_write_b32": "v_add_f32", "v_rsq_f32": "v_rcp_f32",
+    "v_ldexp_f32": "v_mul_f32", "v_bfe_u32": "v_and_or_b32", "v_lshl_add_u32": "v_and_or_b32", "v_lshl_or_b32": "v_and_or_b32",
+    "v_xad_u32": "v_and_or_b32", "v_add_co_u32": "v_add_u32", "v_addc_co_u32": "v_add_u32", "v_mul_u32_u24": "v_add_u32",
+    "v_mad_u32_u24": "v_and_or_b32", "v_readfirstlane_b32": "v_readlane_b32", "v_mul_legacy_f32": "v_mul_f32",
+}
+
+
+def strip(op):
+    return re.sub(r"_(e32|e64|dpp|sdwa|e64_dpp)$", "", op)
+
+
+def compile_tu(tu, flags):
+    tmp = tempfile.mkdtemp(prefix="issue_model_")
+    prefix = "quad_" if tu.startswith("quad_") else "variants_"
+    src = os.path.join(ROOT, "rwm-pt-pytorch_amd", "csrc", f"{prefix}{tu.replace('quad_', '')}.hip")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function",
+                           "-save-temps=obj", "-c", src, "-o", os.path.join(tmp, "v.o")] + flags, stderr=subprocess.DEVNULL, cwd=tmp)
+    return os.path.join(tmp, os.path.basename(src).replace(".hip", "-hip-amdgcn-amd-amdhsa-gfx950.s"))
+
+
+def kernel_blocks(asm_path, flt):
+    lines = open(asm_path).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN5ptrwm") and flt in l.split(":")[0] and ":" in l)
+    end = next(i for i in range(start, len(lines)) if ".end_amdhsa_kernel" in lines[i] or lines[i].startswith(".Lfunc_end"))
+    name = lines[start].split(":")[0]
+    blocks, order, cur = {}, [], None
+    for l in lines[start + 1:end]:
+        m = re.match(r"^(\.LBB\d+_\d+):", l) or re.match(r"^; %bb\.(\d+):", l)
+        if m:
+            cur = m.group(1) if l.startswith(".L") else f"bb.{m.group(1)}"
+            blocks[cur] = {"ins": [], "notes": l, "succ": []}
+            order.append(cur)
+            continue
+        if cur is None:
+            continue
+        if l.lstrip().startswith(";"):
+            blocks[cur]["notes"] += " " + l.strip()
+            continue
+        m = re.match(r"\s+([a-z][a-z0-9_]+)\s*(.*)", l)
+        if m and not m.group(1).startswith("."):
+            blocks[cur]["ins"].append((m.group(1), m.group(2)))
+    for i, b in enumerate(order):
+        ins = blocks[b]["ins"]
+        nxt = order[i + 1] if i + 1 < len(order) else None
+        fall = True
+        for op, args in ins:
+            if op.startswith("s_cbranch"):
+                blocks[b]["succ"].append((op, args.split()[0]))
+            elif op == "s_branch":
+                blocks[b]["succ"].append((op, args.split()[0]))
+                fall = False
+            elif op in ("s_endpgm", "s_setpc_b64"):
+                fall = False
+        if fall and nxt:
+            blocks[b]["succ"].append(("fall", nxt))
+    return name, blocks, order
+
+
+def features(b):
+    ops = [o for o, _ in b["ins"]]
+    return {
+        "lds": sum(o.startswith("ds_") for o in ops), "barrier": sum(o == "s_barrier" for o in ops),
+        "sload": sum(o.startswith("s_load") for o in ops), "inner": int("Depth=2" in b["notes"] or "Depth 2" in b["notes"] and "Child" not in b["notes"]),
+        "global": sum(o.startswith(("global_", "flat_", "buffer_", "scratch_")) for o in ops),
+    }
+
+
+def step_path(blocks, order):
+    loops = [b for b in order if "This Loop Header: Depth=1" in blocks[b]["notes"]]
+    header = max(loops, key=lambda b: sum(o == "v_mad_u64_u32" for o, _ in blocks[b]["ins"]) * 1000 + len(blocks[b]["ins"]))
+    in_loop = {b for b in order if f"Header={header.replace('.L', '')}" in blocks[b]["notes"].replace(" ", "")} | {header}
+    best = [None, None]
+
+    def dfs(b, path, pen):
+        if best[0] is not None and pen > best[0]:
+            return
+        for kind, t in blocks[b]["succ"]:
+            if kind.startswith("s_cbranch_exec"):
+                continue  # a skip over a block for waves without live lanes: not taken
+            if t == header:
+                if best[0] is None or pen < best[0]:
+                    best[0], best[1] = pen, list(path)
+                continue
+            if t not in in_loop or t in path:
+                continue
+            f = features(blocks[t])
+            p = pen + 10 * f["lds"] + 1000 * f["barrier"] + 3 * f["sload"] + 1000 * f["inner"] + 5 * f["global"]
+            dfs(t, path + [t], p)
+
+    dfs(header, [header], 0)
+    if best[1] is None:
+        sys.exit("no path from the step-loop header back to itself found")
+    return header, best[1], best[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tu", default="rough_carpet2")
+    ap.add_argument("--kernel", default=HEADLINE)
+    ap.add_argument("--costs", default=os.path.join(ROOT, "profiles", "r03_issue_costs.json"))
+    ap.add_argument("--waves", default="waves_per_simd_4")
+    ap.add_argument("--valu-per-wave-step", type=float)
+    ap.add_argument("--salu-per-wave-step", type=float)
+    ap.add_argument("--ns-per-wave-step", type=float, help="measured: kernel time x SIMDs / (waves x steps)")
+    ap.add_argument("--flags", default=None, help="compile flags of the TU's group (default: the Makefile's max-ILP group)")
+    ap.add_argument("--asm", default=None, help="an annotated .s to reuse instead of compiling")
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    asm = a.asm or compile_tu(a.tu, a.flags.split() if a.flags is not None else SCHED)
+    name, blocks, order = kernel_blocks(asm, a.kernel)
+    header, path, pen = step_path(blocks, order)
+    ops = collections.Counter()
+    for b in path:
+        for o, _ in blocks[b]["ins"]:
+            ops[strip(o)] += 1
+    valu = sum(c for o, c in ops.items() if o.startswith("v_"))
+    salu = sum(c for o, c in ops.items() if o.startswith("s_") and not o.startswith(("s_waitcnt", "s_nop", "s_load", "s_buffer")))
+    smem = sum(c for o, c in ops.items() if o.startswith(("s_load", "s_buffer")))
+    print(f"kernel {name}\nstep loop header {header}; path of a step without a swap event: {' '.join(path)} (penalty {pen})")
+    print(f"instructions on the path: {sum(ops.values())} = {valu} VALU + {salu} SALU + {smem} scalar loads + "
+          f"{sum(c for o, c in ops.items() if o.startswith('ds_'))} LDS + {ops.get('s_nop', 0)} s_nop + {ops.get('s_waitcnt', 0)} s_waitcnt")
+    ok = True
+    for what, got, want in (("VALU", valu, a.valu_per_wave_step), ("SALU", salu, a.salu_per_wave_step)):
+        if want:
+            rel = got / want - 1
+            print(f"check against the PMC count without swap events: {what} {got} static vs {want:.1f} counted per wave-step ({rel:+.2%})")
+            ok &= abs(rel) < (0.01 if what == "VALU" else 0.05)
+    costs = json.load(open(a.costs))[a.waves] if os.path.exists(a.costs) else {}
+    base = costs.get("v_fma_f32")
+    rows, busy, unpriced = [], 0.0, []
+    for o, c in ops.most_common():
+        if not o.startswith("v_"):
+            continue
+        key = o if o in costs else ALIAS.get(o)
+        ns = costs.get(key) if key else None
+        if ns is None:
+            unpriced.append(o)
+            ns = base
+        if ns is not None:
+            busy += c * ns
+        rows.append((o, c, ns))
+    if costs:
+        print(f"\n{'opcode':24s} {'count':>6s} {'ns each':>8s} {'ns':>9s} {'share':>6s}")
+        for o, c, ns in rows:
+            print(f"{o:24s} {c:6d} {ns:8.3f} {c * ns:9.1f} {c * ns / busy:6.1%}")
+        print(f"busy SIMD time per wave-step (sum of VALU count x measured issue cost): {busy:.1f} ns"
+              + (f"; unpriced opcodes priced as v_fma_f32: {unpriced}" if unpriced else ""))
+        if a.ns_per_wave_step:
+            print(f"measured SIMD time per wave-step: {a.ns_per_wave_step:.1f} ns  ->  cost-weighted issue fraction "
+                  f"{busy / a.ns_per_wave_step:.3f}")
+    if a.json:
+        json.dump({"kernel": name, "path": path, "valu_on_path": valu, "salu_on_path": salu, "histogram": dict(ops),
+                   "busy_ns_per_wave_step": busy if costs else None, "unpriced": unpriced,
+                   "pmc_check": {"valu_per_wave_step": a.valu_per_wave_step, "salu_per_wave_step": a.salu_per_wave_step, "ok": ok},
+                   "ns_per_wave_step": a.ns_per_wave_step,
+                   "issue_cost_weighted": (busy / a.ns_per_wave_step) if (costs and a.ns_per_wave_step) else None,
+                   "costs": os.path.relpath(a.costs, ROOT), "waves": a.waves}, open(a.json, "w"), indent=1)
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
