@@ -196,6 +196,14 @@ typedef struct ptrwm_run_args {
   int32_t trace_every;  /* thinning: a step is traced when step_counter % trace_every == 0 (0 or 1 = every step) */
   int64_t trace_row0;   /* row written by the first traced step of this call */
   uint8_t *accept_flags; /* [n_steps, n_chains, n_temps] MH accept decision of every step, or NULL */
+  /* 0: as declared above.  1 (ptrwm_run only): `state`, `trace` and `ext_prop` point to DOUBLE arrays of the same shapes -
+   * the reference's dtype=torch.float64 (pt_rwm_gpu_optimized.py:134,431-449; experiment_pt_GPU.py:236
+   * --use_double_precision): states, the proposals x + scale * z and the squared-jump sums are carried in double, so a
+   * state far from the origin keeps the low bits of its increments; log-densities (evaluated on the proposal rounded to
+   * float), uniforms, temperatures and proposal scales stay float.  ext_prop in this mode: NORMAL proposal only (the
+   * reference's PT class is Gaussian only).  Always the lane-split form of the kernel; ladders of <= 128 temperatures. */
+  int32_t state_f64;
+  int32_t reserved0; /* must be 0 */
 } ptrwm_run_args;
 
 /* Advance every (chain, temperature) replica by n_steps Metropolis steps (with

@@ -43,6 +43,7 @@ class RunArgs(C.Structure):
         ("ext_prop", C.c_void_p), ("ext_u", C.c_void_p), ("ext_swap_u", C.c_void_p), ("trace", C.c_void_p),
         ("trace_logp", C.c_void_p), ("trace_chains", C.c_int64), ("trace_temps", C.c_int32),
         ("trace_every", C.c_int32), ("trace_row0", C.c_int64), ("accept_flags", C.c_void_p),
+        ("state_f64", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -121,6 +122,16 @@ def philox4x32_10(ctr, key):
 
 
 def logdensity(target: Target, x, precision="f32"):
+    """log-density of every row of x.  float64 input (the states of a state_f64 run) is evaluated as given, in double."""
+    if np.asarray(x).dtype == np.float64 and precision == "f64":
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, target.dim)
+        out = np.empty(x.shape[0], dtype=np.float64)
+        d = target.desc()
+        fn = lib().oracle_logdensity_d_f64
+        fn.restype = C.c_int32
+        rc = fn(C.byref(d), C.c_void_p(x.ctypes.data), C.c_void_p(out.ctypes.data), C.c_int64(x.shape[0]))
+        assert rc == 0, rc
+        return out
     x = _f32(x).reshape(-1, target.dim)
     out = np.empty(x.shape[0], dtype=np.float64)
     d = target.desc()
@@ -164,8 +175,14 @@ def philox_randoms(proposal_kind, dim, n_temps, n_chains, *, seed, step0, n_step
 def run(target: Target, proposal: Proposal, *, state, logp, beta, step0, n_steps, burn_in=0, swap_every=1,
         swap_mode=SWAP_EXCHANGE, swap_order=ORDER_SEQUENTIAL, seed=0, chain_offset=0, ext_prop=None, ext_u=None,
         ext_swap_u=None, trace_chains=0, trace_temps=0, want_flags=False, precision="f32", swap_event_offset=0):
-    """Runs the oracle.  Returns a dict with the updated state/logp (float32 copies) and statistics."""
-    state = np.array(state, dtype=np.float32, order="C", copy=True)
+    """Runs the oracle.  Returns a dict with the updated state/logp (copies) and statistics.  A float64 `state` selects the
+    state_f64 mode of include/ptrwm.h (the reference's dtype=torch.float64): state, trace and ext_prop in double, and the
+    double-precision instantiation of the oracle (precision is forced to "f64")."""
+    sf = np.asarray(state).dtype == np.float64
+    sdt = np.float64 if sf else np.float32
+    if sf:
+        precision = "f64"
+    state = np.array(state, dtype=sdt, order="C", copy=True)
     Cn, T, D = state.shape
     logp = np.array(logp, dtype=np.float32, order="C", copy=True).reshape(Cn, T)
     beta = _f32(beta)
@@ -184,10 +201,12 @@ def run(target: Target, proposal: Proposal, *, state, logp, beta, step0, n_steps
     a.step0, a.n_steps, a.burn_in = step0, n_steps, burn_in
     a.swap_every, a.swap_mode, a.swap_order, a.seed = swap_every, swap_mode, swap_order, seed
     a.swap_event_offset = swap_event_offset
-    ext_prop, ext_u, ext_swap_u = _f32(ext_prop), _f32(ext_u), _f32(ext_swap_u)
+    a.state_f64 = 1 if sf else 0
+    ext_prop = (None if ext_prop is None else np.ascontiguousarray(ext_prop, dtype=np.float64)) if sf else _f32(ext_prop)
+    ext_u, ext_swap_u = _f32(ext_u), _f32(ext_swap_u)
     a.ext_prop, a.ext_u, a.ext_swap_u = _ptr(ext_prop), _ptr(ext_u), _ptr(ext_swap_u)
     if trace_chains:
-        res["trace"] = np.zeros((n_steps, trace_chains, trace_temps, D), dtype=np.float32)
+        res["trace"] = np.zeros((n_steps, trace_chains, trace_temps, D), dtype=sdt)
         res["trace_logp"] = np.zeros((n_steps, trace_chains, trace_temps), dtype=np.float32)
         a.trace, a.trace_logp = res["trace"].ctypes.data, res["trace_logp"].ctypes.data
         a.trace_chains, a.trace_temps = trace_chains, trace_temps

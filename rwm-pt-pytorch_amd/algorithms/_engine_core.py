@@ -40,7 +40,8 @@ def draw_seed() -> int:
 class EngineRun:
     def __init__(self, *, target_dist, proposal: "ptrwm_hip.Proposal", beta_ladder: Sequence[float], dim: int,
                  device: torch.device, n_replicas: int, initial_state: np.ndarray, burn_in: int, swap_every: int,
-                 swap_mode: str, swap_order: str, seed: Optional[int], chain_offset: int = 0):
+                 swap_mode: str, swap_order: str, seed: Optional[int], chain_offset: int = 0,
+                 dtype: torch.dtype = torch.float32):
         if swap_mode not in ptrwm_hip.SWAP_MODES:
             raise ValueError(f"swap_mode must be one of {sorted(ptrwm_hip.SWAP_MODES)}, got {swap_mode!r}")
         if swap_order not in ptrwm_hip.SWAP_ORDERS:
@@ -83,10 +84,17 @@ class EngineRun:
         self.steps_done = 0
         self.manual_sweeps = 0  # stand-alone swap events (swap_sweep) performed so far
         self.beta = torch.tensor(list(beta_ladder), device=device, dtype=torch.float32)
-        x0 = torch.as_tensor(np.asarray(initial_state), dtype=torch.float32).to(device)
+        if dtype not in (torch.float32, torch.float64):
+            raise TypeError(f"state dtype must be torch.float32 or torch.float64, got {dtype}")
+        if dtype == torch.float64 and self.density_fn is not None:
+            raise NotImplementedError("dtype=torch.float64 needs a target with a fused kernel (split steps carry float32 "
+                                      "states)")
+        self.dtype = dtype  # float64: the engine's state_f64 mode (the reference's dtype=torch.float64)
+        x0 = torch.as_tensor(np.asarray(initial_state), dtype=dtype).to(device)
         # every temperature (and replica) starts from the same point (pt_rwm_gpu_optimized.py:478-484)
         self.state = x0.expand(n_replicas, n_temps, dim).contiguous()
-        self.logp = self._density(self.state.view(-1, dim)).view(n_replicas, n_temps).contiguous()
+        # (log-densities are float32 in either mode: the density kernels evaluate the state rounded to float)
+        self.logp = self._density(self.state.view(-1, dim).to(torch.float32)).view(n_replicas, n_temps).contiguous()
         shape = (n_replicas, n_temps)
         self.n_accept = torch.zeros(shape, device=device, dtype=torch.int64)
         self.sq_jump = torch.zeros(shape, device=device, dtype=torch.float64)

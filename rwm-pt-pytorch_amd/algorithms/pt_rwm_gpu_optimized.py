@@ -57,9 +57,13 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
                  chain_offset: int = 0, trace: str = "all", thin: int = 1):
         super().__init__(dim, var, target_dist, symmetric)
         self.device = resolve_device(device)
-        if dtype != torch.float32:
-            warnings.warn(f"dtype={dtype} requested; the fused kernel computes and stores states in float32")
-        self.dtype = torch.float32
+        # dtype=torch.float64 (experiment_pt_GPU.py:236 --use_double_precision; pt_rwm_gpu_optimized.py:134,431-449): states,
+        # proposals x + scale * z, stored chains and jump distances in double (the engine's state_f64 mode: lane-split
+        # kernel with double state registers); log-densities, temperatures and proposal scales stay float32 as the
+        # reference allocates them (:436-442,:453-455).  Any other dtype is an error, as torch would raise further down.
+        if dtype not in (torch.float32, torch.float64):
+            raise TypeError(f"dtype must be torch.float32 or torch.float64, got {dtype}")
+        self.dtype = dtype
         self.burn_in = max(0, burn_in)
         self.swap_every = swap_every
         self.ideal_swap_acceptance_rate = swap_acceptance_rate
@@ -101,7 +105,7 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
         if proposal_distribution is None:
             if var is None or var <= 0:
                 raise ValueError("var must be a positive proposal variance")
-            proposal_distribution = NormalProposal(dim, var, 1.0, self.device, self.dtype, None)
+            proposal_distribution = NormalProposal(dim, var, 1.0, self.device, torch.float32, None)
         elif not isinstance(proposal_distribution, (NormalProposal, LaplaceProposal, UniformRadiusProposal)):
             raise TypeError(f"{type(proposal_distribution).__name__} is not implemented by the fused kernel")
         self.proposal_dist = proposal_distribution
@@ -205,7 +209,8 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
             target_dist=self.target_dist, proposal=self.proposal_dist.engine_proposal(self.beta_ladder),
             beta_ladder=self.beta_ladder, dim=self.dim, device=self.device, n_replicas=self.num_replicas,
             initial_state=self._initial_state, burn_in=self.burn_in, swap_every=self.swap_every,
-            swap_mode=self._swap_mode, swap_order=self._swap_order, seed=self._seed, chain_offset=self._chain_offset)
+            swap_mode=self._swap_mode, swap_order=self._swap_order, seed=self._seed, chain_offset=self._chain_offset,
+            dtype=self.dtype)
         # reference shapes for one ladder: [T, dim] / [T]; with replicas: [R, T, dim] / [R, T]
         self.current_states = self._run.state[0] if self.num_replicas == 1 else self._run.state
         self.current_log_densities = self._run.logp[0] if self.num_replicas == 1 else self._run.logp

@@ -450,11 +450,14 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
     return PTRWM_E_ARG;
   if (args->swap_mode != PTRWM_SWAP_EXCHANGE && args->swap_mode != PTRWM_SWAP_REFERENCE_COPY) return PTRWM_E_ARG;
   if (args->swap_order != PTRWM_ORDER_SEQUENTIAL && args->swap_order != PTRWM_ORDER_EVEN_ODD) return PTRWM_E_ARG;
+  if ((args->state_f64 != 0 && args->state_f64 != 1) || args->reserved0 != 0) return PTRWM_E_ARG;
   if (args->n_chains == 0 || args->n_steps == 0) return PTRWM_OK;  // empty batch: nothing to touch
   if (args->state == nullptr || args->logp == nullptr || args->beta == nullptr || proposal->temp_scale == nullptr)
     return PTRWM_E_NULL;
   if (proposal->kind == PTRWM_PROPOSAL_LAPLACE && proposal->dim_scale == nullptr) return PTRWM_E_NULL;
   const bool ext = args->ext_prop != nullptr;
+  const bool f64 = args->state_f64 == 1;  // double state / trace / ext_prop (include/ptrwm.h): lane-split form only
+  if (f64 && ext && proposal->kind != PTRWM_PROPOSAL_NORMAL) return PTRWM_E_ARG;
   if (ext && args->ext_u == nullptr) return PTRWM_E_NULL;
   if (args->trace != nullptr && (args->trace_chains < 1 || args->trace_temps < 1 || args->trace_row0 < 0 ||
                                  args->trace_temps > args->n_temps || args->trace_chains > args->n_chains ||
@@ -471,9 +474,13 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   bool quad = false;
   {
     const int qi = quad_index_for(target->dim, args->n_temps);
-    const RunLaunchFn qfn = qi >= 0 ? quad_variants(target->kind, two_term).run[proposal->kind][qi] : nullptr;
+    const QuadVariants &qv = quad_variants(target->kind, two_term);
+    const RunLaunchFn qfn = qi >= 0 ? (f64 ? qv.run_f64 : qv.run)[proposal->kind][qi] : nullptr;
     const int form = __atomic_load_n(&g_kernel_form, __ATOMIC_RELAXED);
-    if (qfn != nullptr && (fn == nullptr || form != PTRWM_FORM_THREAD)) {
+    if (f64) {
+      fn = qfn;  // the only form with double state registers (null: ladder too long for a 512-thread workgroup)
+      quad = true;
+    } else if (qfn != nullptr && (fn == nullptr || form != PTRWM_FORM_THREAD)) {
       const long long cpw1 = args->n_temps > 64 ? 1 : 64 / args->n_temps;
       const long long waves1 = args->n_temps > 64 ? args->n_chains * ((args->n_temps + 63) / 64)
                                                   : (args->n_chains + cpw1 - 1) / cpw1;
@@ -559,7 +566,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
     k.burn_left = burn_left <= 0 ? 0 : (burn_left > n ? (int)n : (int)burn_left);
     k.first_swap_event = ev0 + args->swap_event_offset;
     k.steps_to_swap = (int)(se - step0 % se);
-    k.full.ext_prop = ext ? args->ext_prop + done * reps * raw : nullptr;
+    k.full.ext_prop = ext ? args->ext_prop + done * reps * raw * (f64 ? 2 : 1) : nullptr;  // (f64: a double array)
     k.full.ext_u = ext ? args->ext_u + done * reps : nullptr;
     k.full.ext_swap_u = (ext && args->ext_swap_u != nullptr)
                             ? args->ext_swap_u + (ev0 - events_upto(args->step0)) * args->n_chains * (args->n_temps - 1)
@@ -579,6 +586,7 @@ int32_t ptrwm_swap_sweep(const ptrwm_run_args *args, int32_t dim, int64_t event_
                          void *stream) {
   if (args == nullptr) return PTRWM_E_NULL;
   if (args->struct_size != sizeof(ptrwm_run_args)) return PTRWM_E_STRUCT;
+  if (args->state_f64 != 0 || args->reserved0 != 0) return PTRWM_E_ARG;  // float states only
   if (dim < 1 || dim > PTRWM_MAX_DIM) return PTRWM_E_DIM;
   if (args->n_temps < 1 || args->n_temps > PTRWM_MAX_TEMPS) return PTRWM_E_TEMPS;
   if (args->n_chains < 0 || args->n_chains > 0x7fffffffll || args->step0 < 0 || event_index < 0 || rng_stream < 1 ||
@@ -594,6 +602,7 @@ int32_t ptrwm_swap_sweep(const ptrwm_run_args *args, int32_t dim, int64_t event_
 static int32_t split_common_checks(const ptrwm_run_args *args, int32_t dim) {
   if (args == nullptr) return PTRWM_E_NULL;
   if (args->struct_size != sizeof(ptrwm_run_args)) return PTRWM_E_STRUCT;
+  if (args->state_f64 != 0 || args->reserved0 != 0) return PTRWM_E_ARG;  // float states only
   if (dim < 1 || dim > PTRWM_MAX_DIM) return PTRWM_E_DIM;
   if (args->n_temps < 1 || args->n_temps > PTRWM_MAX_TEMPS) return PTRWM_E_TEMPS;
   if (args->n_chains < 0 || args->n_chains > 0x7fffffffll || args->step0 < 0 || args->burn_in < 0 ||

@@ -232,6 +232,17 @@ __device__ __forceinline__ int fresh_dim(int d0) {
   return d0;
 }
 
+// The kernel's arguments as they sit in the kernarg segment (KArgs is the kernel's only parameter: offset 0), through a
+// pointer the optimiser cannot relate to `a`: what is read through it is loaded where it is used - one s_load in the
+// epilogue - instead of being loaded at kernel entry and held in SGPRs, i.e. in spill lanes, across the whole step loop
+// (the epilogue alone needs eight pointers and three scalars: ~20 SGPRs of the 102 a wave has).
+typedef const __attribute__((address_space(4))) KArgs *kargs_ptr;
+__device__ __forceinline__ kargs_ptr late_args() {
+  uintptr_t p = (uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return (kargs_ptr)p;
+}
+
 // Register budget: the replica's x[DP] and y[DP] plus ~30 temporaries must stay in VGPRs.  Without a
 // bound hipcc hoists every Philox block of a step ahead of its consumers and lands far above that.
 #ifndef PTRWM_J2_FENCE_MASK  // fence cadence of the update / squared-jump loop (A/B-timed, tools/ab_bench.sh)
@@ -482,6 +493,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
   }
 
   // ---- state store: rows -> LDS slab -> coalesced HBM writes -----------------------------------------------
+  const kargs_ptr ae = late_args();  // the epilogue's arguments are loaded here, not kept in SGPRs across the step loop
   long long c0_out;
   {
     // everything is recomputed from opaque copies so that nothing of the prologue stays live across the step loop
@@ -491,11 +503,12 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     float *const rows2 = s_dyn + (wide2 ? 0 : (int)(threadIdx.x >> 6) * (64 * (DP + kLdsExtraPerThread)));
     const long long bid = (long long)fresh_dim<false>((int)blockIdx.x);  // re-read here, not carried in a VGPR
     const long long c0 = (wide2 ? bid : bid * kWavesPerBlock + (threadIdx.x >> 6)) * cpw2;
-    const long long live_chains = (a.n_chains - c0 < cpw2) ? (a.n_chains - c0) : cpw2;
+    const long long n_chains2 = ae->n_chains;
+    const long long live_chains = (n_chains2 - c0 < cpw2) ? (n_chains2 - c0) : cpw2;
     const int stage_total = (int)live_chains * T2 * D2;
     const long long stage_g0 = c0 * T2 * (long long)D2;
     c0_out = c0;
-    float *__restrict__ gs = a.state + stage_g0;
+    float *__restrict__ gs = ae->state + stage_g0;
     sync_group();  // the last swap's row reads are done before the rows are overwritten
     if (live) {
       float *row = rows2 + stage_head(gs) + tid2 * D2;
@@ -517,18 +530,18 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     const int t = park[0] & 0xff;
     const unsigned n_swap_acc = (unsigned)park[gt_o];
     const int last_event = park[2 * gt_o];
-    a.logp[rep] = lp;
+    ae->logp[rep] = lp;
     // statistics: read-modify-write only where this launch has something to add (a launch without a swap event - nine in
     // ten at one step per launch - then leaves the swap counters' cache lines alone)
-    if (a.n_accept != nullptr && n_acc != 0u) a.n_accept[rep] += (long long)n_acc;
-    if (a.sq_jump != nullptr && sq != 0.0) a.sq_jump[rep] += sq;
-    if (a.swap_accept != nullptr && n_swap_acc != 0u) a.swap_accept[rep] += (long long)n_swap_acc;
-    if (a.last_swap_ordinal != nullptr && last_event >= 0) {
+    if (ae->n_accept != nullptr && n_acc != 0u) ae->n_accept[rep] += (long long)n_acc;
+    if (ae->sq_jump != nullptr && sq != 0.0) ae->sq_jump[rep] += sq;
+    if (ae->swap_accept != nullptr && n_swap_acc != 0u) ae->swap_accept[rep] += (long long)n_swap_acc;
+    if (ae->last_swap_ordinal != nullptr && last_event >= 0) {
       // 1-based attempt ordinal counted from the start of the run.  Sequential order: T-1 attempts
       // per event; even/odd events have a varying pair count, so the event number is recorded.
-      const long long ev = a.first_swap_event + last_event;
-      const long long ord = (a.swap_order == PTRWM_ORDER_SEQUENTIAL) ? ev * (T - 1) + t + 1 : ev + 1;
-      if (ord > a.last_swap_ordinal[rep]) a.last_swap_ordinal[rep] = ord;
+      const long long ev = ae->first_swap_event + last_event;
+      const long long ord = (ae->swap_order == PTRWM_ORDER_SEQUENTIAL) ? ev * (T_o - 1) + t + 1 : ev + 1;
+      if (ord > ae->last_swap_ordinal[rep]) ae->last_swap_ordinal[rep] = ord;
     }
   }
 }

@@ -85,6 +85,14 @@ __device__ __forceinline__ const_float_ptr uniform_vec(const float *p) {
   return (const_float_ptr)v;
 }
 
+// the same pointer, re-materialised: scalar loads through it cannot be merged with, or hoisted above, loads issued before
+// this point - used every few dimensions to bound how many parameter words are in flight (in SGPRs) at once
+__device__ __forceinline__ const_float_ptr uniform_vec_again(const_float_ptr p) {
+  uintptr_t v = (uintptr_t)p;
+  asm volatile("" : "+s"(v));
+  return (const_float_ptr)v;
+}
+
 // top 24 bits -> [0, 1): same lattice as torch.rand(float32)
 __device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * 0x1p-24f; }
 // top 24 bits -> (0, 1]

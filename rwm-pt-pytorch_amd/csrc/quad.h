@@ -555,20 +555,61 @@ struct QNealFunnel {
 };
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------
-// dynamic LDS bytes of a workgroup: per replica slot a row of up to 4 W floats plus the six words of kernel.h's swap
-// machinery (log-density, swap uniform, outcome; three spare) -> (W + 2) floats per thread
-constexpr unsigned quad_kernel_lds_bytes(int threads, int w) { return (unsigned)(threads * (w + 2)) * 4u; }
+// dynamic LDS bytes of a workgroup: per replica slot a row of up to 4 W state elements (float, or double in the F64 form)
+// plus the six words of kernel.h's swap machinery (log-density, swap uniform, outcome; three spare)
+// -> (W * words-per-element + 2) floats per thread
+constexpr unsigned quad_kernel_lds_bytes(int threads, int w, bool f64 = false) {
+  return (unsigned)(threads * (w * (f64 ? 2 : 1) + 2)) * 4u;
+}
 // Widest workgroup = one ladder.  Every variant is compiled for workgroups of up to 512 threads (ladders of <= 128
 // temperatures: up to 256 VGPRs, no spills); the W >= 20 classes (dim > 64), where this is the ONLY form of the fused kernel,
 // are also compiled for 1024 threads (ladders of <= 256 temperatures: 128 VGPRs, a dozen of them spilled).
 constexpr int kQuadThreads = 512;
 constexpr int kQuadThreadsMax = 1024;
 
+// double-precision pieces of the F64 form: IEEE ops the compiler must not contract (the state update x + scale * z is then
+// bit-identical to the reference's two float64 torch ops), and the canonical quad combination on 64-bit values
+__device__ __forceinline__ double dmul_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ double dadd_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ double dsub_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(dpp_i<CTRL>(hi), dpp_i<CTRL>(lo));
+}
+__device__ __forceinline__ double quad_tree_add(double p) {
+  const double t = dadd_rn(p, dpp_d<kDppSwapPair>(p));
+  return dadd_rn(t, dpp_d<kDppSwapHalf>(t));
+}
+template <bool F64>
+struct quad_state {
+  typedef float type;
+};
+template <>
+struct quad_state<true> {
+  typedef double type;
+};
+
 // W      lane register width = canonical range width (8 / 16 / 20 / 24 / 28)
 // DEXACT dim compiled in (0: run-time dim, any value the width class covers)
 // MAXT   largest workgroup the variant may be launched with (kQuadThreads or kQuadThreadsMax)
-template <class Target, class Proposal, int W, int DEXACT, int MAXT, bool FULL>
+// F64    state_f64 of include/ptrwm.h - the reference's dtype=torch.float64 (pt_rwm_gpu_optimized.py:134,431-449): the state,
+//        the proposal x + scale * z and the squared jump are carried in double (a.state / trace / ext_prop are double arrays);
+//        the increment itself comes from the float proposal functor (Philox) or, with external randoms, is the reference's
+//        double product of the float scale and a double normal; the log-density is evaluated on the proposal rounded to float
+template <class Target, class Proposal, int W, int DEXACT, int MAXT, bool FULL, bool F64 = false>
 __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
+  typedef typename quad_state<F64>::type state_t;
+  constexpr int SW = F64 ? 2 : 1;  // 32-bit words per state element
   const int T = a.n_temps;
   const int D = DEXACT ? DEXACT : a.dim;
   const int cpw = a.chains_per_wave;  // ladders per exchange group (narrow: 16 / T per wave; wide: per workgroup)
@@ -598,8 +639,9 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
   const long long rep = chain0 * T + slot;
 
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-  float *const rows = s_dyn + (wide ? 0 : (int)(threadIdx.x >> 6) * (64 * (W + 2)));
-  float *const s_l = rows + nslots * (4 * W);
+  float *const rows_f = s_dyn + (wide ? 0 : (int)(threadIdx.x >> 6) * (64 * (W * SW + 2)));
+  state_t *const rows = reinterpret_cast<state_t *>(rows_f);
+  float *const s_l = rows_f + nslots * (4 * W * SW);
   float *const s_u = s_l + nslots;
   int *const s_landed = reinterpret_cast<int *>(s_u + nslots);
   auto sync_group = [&]() {
@@ -612,20 +654,24 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
   };
   constexpr int MIN_OWN = DEXACT ? (DEXACT - 3 * W > 0 ? (DEXACT - 3 * W > W ? W : DEXACT - 3 * W) : 0) : -1;
 
-  // ---- state load: the group's live replicas are one contiguous run of floats: coalesced copy into the slab, then
-  // every lane picks its quarter of its replica's row (row stride = dim)
-  float x[W], y[W];
+  // ---- state load: the group's live replicas are one contiguous run of elements: coalesced copy into the slab (as 32-bit
+  // words: two per element in the F64 form, whose runs start 8-byte aligned, so the slab offset stage_head is even),
+  // then every lane picks its quarter of its replica's row (row stride = dim)
+  state_t x[W];
+  float y[W];
+  [[maybe_unused]] double yd[F64 ? W : 1];
   {
     const long long live_chains = (a.n_chains - chain0 < cpw) ? (a.n_chains - chain0) : cpw;
-    const int stage_total = (int)live_chains * T * D;
-    float *__restrict__ gs = a.state + chain0 * T * (long long)D;
-    stage_copy<true>(rows, gs, stage_total, tid, gthreads);
+    const int stage_total = (int)live_chains * T * D * SW;
+    float *__restrict__ gs = a.state + chain0 * T * (long long)D * SW;
+    stage_copy<true>(rows_f, gs, stage_total, tid, gthreads);
     sync_group();
-    const float *seg = rows + stage_head(gs) + slot * D + l.d0;
+    const state_t *seg = reinterpret_cast<const state_t *>(rows_f + stage_head(gs)) + slot * D + l.d0;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-      x[j] = q_valid<MIN_OWN>(l, j) ? seg[j] : 0.0f;
+      x[j] = q_valid<MIN_OWN>(l, j) ? seg[j] : (state_t)0;
       y[j] = 0.0f;
+      if constexpr (F64) yd[j] = 0.0;
     }
   }
   float lp = a.logp[rep];
@@ -670,12 +716,37 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
     if constexpr (FULL) {
       srep = ((long long)i * a.n_chains + chain) * T + t;
       if (ext) {
-        ext_rep = a.full.ext_prop + srep * a.full.n_raw_ext;
+        ext_rep = a.full.ext_prop + srep * a.full.n_raw_ext * SW;
         ext_u = a.full.ext_u[srep];
       }
     }
 
-    const float u_acc = Proposal::propose(y, x, l, D, tscale, a.pp, rc, ext_rep, ext_u);
+    float u_acc;
+    if constexpr (!F64) {
+      u_acc = Proposal::propose(y, x, l, D, tscale, a.pp, rc, ext_rep, ext_u);
+    } else {
+      if (ext_rep != nullptr) {
+        // the reference's float64 path: increments = bmm(diag(scale).double(), randn(float64)); proposals = states +
+        // increments (pt_rwm_gpu_optimized.py:445-455,546-547,576-592): one double product, one double sum
+        const double *er = reinterpret_cast<const double *>(ext_rep) + l.d0;
+        const double ts = (double)tscale;
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+          if (q_valid<MIN_OWN>(l, j)) yd[j] = dadd_rn(x[j], dmul_rn(er[j], ts));
+        u_acc = ext_u;
+      } else {
+        // Philox: the float proposal functor run from the origin gives the increment; the sum with the state is double
+        float zero[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) zero[j] = 0.0f;
+        u_acc = Proposal::propose(y, zero, l, D, tscale, a.pp, rc, nullptr, 0.0f);
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+          if (q_valid<MIN_OWN>(l, j)) yd[j] = dadd_rn(x[j], (double)y[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < W; ++j) y[j] = q_valid<MIN_OWN>(l, j) ? (float)yd[j] : 0.0f;  // what the density is evaluated on
+    }
     const float lp_new = Target::logp(y, l, D, a.tp);
 
     const bool acc = mh_accept(beta_t, lp_new, lp, u_acc);
@@ -684,19 +755,25 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
       if (a.full.accept_flags != nullptr && live && l.q == 0) a.full.accept_flags[srep] = acc ? 1 : 0;
     }
 
-    float j2l = 0.0f;  // this lane's range of the squared jump
-    float j2;
+    state_t j2l = 0;  // this lane's range of the squared jump
+    state_t j2;
     if (!swap_due) {
 #pragma unroll
       for (int j = 0; j < W; ++j) {
         if (q_valid<MIN_OWN>(l, j)) {
-          const float dl = sub_rn(y[j], x[j]);
-          j2l = fmaf(dl, dl, j2l);
-          x[j] = acc ? y[j] : x[j];
+          if constexpr (F64) {
+            const double dl = dsub_rn(yd[j], x[j]);
+            j2l = __builtin_fma(dl, dl, j2l);
+            x[j] = acc ? yd[j] : x[j];
+          } else {
+            const float dl = sub_rn(y[j], x[j]);
+            j2l = fmaf(dl, dl, j2l);
+            x[j] = acc ? y[j] : x[j];
+          }
         }
       }
       j2 = quad_tree_add(j2l);
-      if (!acc) j2 = 0.0f;
+      if (!acc) j2 = 0;
       lp = lp_mh;
     } else {
       // ---- temperature swaps on the post-MH log-densities: kernel.h's swap_decide over replica slots ----------
@@ -750,18 +827,26 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
         last_event = swap_in_call;
       }
       {
-        float *my_seg = rows + slot_raw * D + l.d0;
+        state_t *my_seg = rows + slot_raw * D + l.d0;
 #pragma unroll
         for (int j = 0; j < W; ++j)
-          if (q_valid<MIN_OWN>(l, j)) my_seg[j] = acc ? y[j] : x[j];
+          if (q_valid<MIN_OWN>(l, j)) {
+            if constexpr (F64) my_seg[j] = acc ? yd[j] : x[j];
+            else my_seg[j] = acc ? y[j] : x[j];
+          }
         sync_group();
-        const float *src_seg = rows + src * D + l.d0;
+        const state_t *src_seg = rows + src * D + l.d0;
 #pragma unroll
         for (int j = 0; j < W; ++j) {
           if (q_valid<MIN_OWN>(l, j)) {
-            const float w = src_seg[j];
-            const float dl = sub_rn(w, x[j]);
-            j2l = fmaf(dl, dl, j2l);
+            const state_t w = src_seg[j];
+            if constexpr (F64) {
+              const double dl = dsub_rn(w, x[j]);
+              j2l = __builtin_fma(dl, dl, j2l);
+            } else {
+              const float dl = sub_rn(w, x[j]);
+              j2l = fmaf(dl, dl, j2l);
+            }
             x[j] = w;
           }
         }
@@ -784,7 +869,7 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
       }
       if (trace_now && trace_on) {
         const long long row = ((a.full.trace_row0 + trace_rows) * a.full.trace_chains + chain) * a.full.trace_temps + t;
-        float *__restrict__ tr = a.full.trace + row * D + l.d0;
+        state_t *__restrict__ tr = reinterpret_cast<state_t *>(a.full.trace) + row * D + l.d0;
 #pragma unroll
         for (int j = 0; j < W; ++j)
           if (q_valid<MIN_OWN>(l, j)) tr[j] = x[j];
@@ -795,29 +880,31 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
   }
 
   // ---- state store: quarters -> slab rows -> coalesced HBM writes ---------------------------------------------
+  const kargs_ptr ae = late_args();  // (kernel.h) the epilogue's arguments are loaded here, not held across the step loop
   {
-    const long long live_chains = (a.n_chains - chain0 < cpw) ? (a.n_chains - chain0) : cpw;
-    const int stage_total = (int)live_chains * T * D;
-    float *__restrict__ gs = a.state + chain0 * T * (long long)D;
+    const long long n_chains2 = ae->n_chains;
+    const long long live_chains = (n_chains2 - chain0 < cpw) ? (n_chains2 - chain0) : cpw;
+    const int stage_total = (int)live_chains * T * D * SW;
+    float *__restrict__ gs = ae->state + chain0 * T * (long long)D * SW;
     sync_group();  // the last swap's row reads are done before the rows are overwritten
     if (live) {
-      float *seg = rows + stage_head(gs) + slot * D + l.d0;
+      state_t *seg = reinterpret_cast<state_t *>(rows_f + stage_head(gs)) + slot * D + l.d0;
 #pragma unroll
       for (int j = 0; j < W; ++j)
         if (q_valid<MIN_OWN>(l, j)) seg[j] = x[j];
     }
     sync_group();
-    stage_copy<false>(rows, gs, stage_total, tid, gthreads);
+    stage_copy<false>(rows_f, gs, stage_total, tid, gthreads);
   }
   if (live && l.q == 0) {
-    a.logp[rep] = lp;
-    if (a.n_accept != nullptr && n_acc != 0u) a.n_accept[rep] += (long long)n_acc;  // (kernel.h: RMW only where there is a delta)
-    if (a.sq_jump != nullptr && sq != 0.0) a.sq_jump[rep] += sq;
-    if (a.swap_accept != nullptr && n_swap_acc != 0u) a.swap_accept[rep] += (long long)n_swap_acc;
-    if (a.last_swap_ordinal != nullptr && last_event >= 0) {
-      const long long ev = a.first_swap_event + last_event;
-      const long long ord = (a.swap_order == PTRWM_ORDER_SEQUENTIAL) ? ev * (T - 1) + t + 1 : ev + 1;
-      if (ord > a.last_swap_ordinal[rep]) a.last_swap_ordinal[rep] = ord;
+    ae->logp[rep] = lp;
+    if (ae->n_accept != nullptr && n_acc != 0u) ae->n_accept[rep] += (long long)n_acc;  // (kernel.h: RMW only where there is a delta)
+    if (ae->sq_jump != nullptr && sq != 0.0) ae->sq_jump[rep] += sq;
+    if (ae->swap_accept != nullptr && n_swap_acc != 0u) ae->swap_accept[rep] += (long long)n_swap_acc;
+    if (ae->last_swap_ordinal != nullptr && last_event >= 0) {
+      const long long ev = ae->first_swap_event + last_event;
+      const long long ord = (ae->swap_order == PTRWM_ORDER_SEQUENTIAL) ? ev * (T - 1) + t + 1 : ev + 1;
+      if (ord > ae->last_swap_ordinal[rep]) ae->last_swap_ordinal[rep] = ord;
     }
   }
 }

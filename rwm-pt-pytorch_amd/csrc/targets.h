@@ -127,9 +127,13 @@ struct ThreeMixture {
   __device__ __forceinline__ static float logp_impl(const float (&y)[DP], int D, const TParams &tp) {
     constexpr int W = canon_width(DP);
     float q0p[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q1p[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    const const_float_ptr uv0 = uniform_vec(tp.vec0);
+    const_float_ptr uv0 = uniform_vec(tp.vec0);
     [[maybe_unused]] const const_float_ptr uv1 = SCALED ? uniform_vec(tp.vec1) : nullptr;
     PTRWM_DIM_LOOP(d, DP, D, {
+      // three mean vectors: 3 dim scalar words per evaluation.  Loaded in one go they overflow the SGPR file (81 spilled
+      // SGPRs and spill-lane VGPRs in scratch at dim 30); re-materialising the pointer every 8 dimensions keeps <= 24 words
+      // in flight (tools/kernel_stats.py)
+      if (d > 0 && (d & 7) == 0) uv0 = uniform_vec_again(uv0);
       float e0, e1, e2;
       if constexpr (SCALED) {
         const float sc = uv1[d];  // s x - mu_k as one explicit fma each, the same in every kernel

@@ -177,6 +177,7 @@ inline int quad_index_for(int dim, int n_temps) {
 
 struct QuadVariants {
   RunLaunchFn run[PTRWM_PROPOSAL_COUNT][kNumQuadWidths];
+  RunLaunchFn run_f64[PTRWM_PROPOSAL_COUNT][kNumQuadWidths];  // state_f64 twins (null for the 1024-thread workgroup class)
 };
 
 // MIN_OWN of quad.h: the number of dimensions the LAST lane owns when dim is compiled in (every lane owns at least
@@ -185,18 +186,18 @@ constexpr int quad_min_own(int w, int dexact) {
   return dexact == 0 ? -1 : (dexact - 3 * w <= 0 ? 0 : (dexact - 3 * w > w ? w : dexact - 3 * w));
 }
 
-template <class Target, class Proposal, int W, int DEXACT, int MAXT>
+template <class Target, class Proposal, int W, int DEXACT, int MAXT, bool F64 = false>
 hipError_t launch_run_quad(const KArgs &a, unsigned grid, bool full, hipStream_t stream) {
   // narrow ladders (4 T <= 64): four independent one-wave groups per workgroup; wide ones: one ladder per workgroup
   const unsigned block = (unsigned)quad_block_threads(a.n_temps);
   if ((int)block > MAXT) return hipErrorInvalidConfiguration;
-  const unsigned lds = quad_kernel_lds_bytes((int)block, W);
-  auto kfull = ptrwm_quad_step_kernel<Target, Proposal, W, DEXACT, MAXT, true>;
-  auto kprod = ptrwm_quad_step_kernel<Target, Proposal, W, DEXACT, MAXT, false>;
+  const unsigned lds = quad_kernel_lds_bytes((int)block, W, F64);
+  auto kfull = ptrwm_quad_step_kernel<Target, Proposal, W, DEXACT, MAXT, true, F64>;
+  auto kprod = ptrwm_quad_step_kernel<Target, Proposal, W, DEXACT, MAXT, false, F64>;
   if (lds > 48u * 1024u) {
     static unsigned long long raised_mask = 0;
     const hipError_t e = raise_dynamic_lds((const void *)kfull, (const void *)kprod,
-                                           (int)quad_kernel_lds_bytes(MAXT, W), raised_mask);
+                                           (int)quad_kernel_lds_bytes(MAXT, W, F64), raised_mask);
     if (e != hipSuccess) return e;
   }
   if (full)
@@ -209,6 +210,16 @@ hipError_t launch_run_quad(const KArgs &a, unsigned grid, bool full, hipStream_t
 #define PTRWM_X_QRUN_N(W, E, M) launch_run_quad<QTGT<W, quad_min_own(W, E)>, QNormal<W, quad_min_own(W, E)>, W, E, M>,
 #define PTRWM_X_QRUN_L(W, E, M) launch_run_quad<QTGT<W, quad_min_own(W, E)>, QLaplace<W, quad_min_own(W, E)>, W, E, M>,
 #define PTRWM_X_QRUN_U(W, E, M) launch_run_quad<QTGT<W, quad_min_own(W, E)>, QUniformRadius<W, quad_min_own(W, E)>, W, E, M>,
+// the state_f64 twin of a variant (include/ptrwm.h): workgroups of up to 512 threads only - twice the state registers
+// do not fit the 128-VGPR budget of a 1024-thread workgroup
+template <class Target, class Proposal, int W, int DEXACT, int MAXT>
+constexpr RunLaunchFn quad_f64_entry() {
+  if constexpr (MAXT > kQuadThreads) return nullptr;
+  else return launch_run_quad<Target, Proposal, W, DEXACT, MAXT, true>;
+}
+#define PTRWM_X_QRUN64_N(W, E, M) quad_f64_entry<QTGT<W, quad_min_own(W, E)>, QNormal<W, quad_min_own(W, E)>, W, E, M>(),
+#define PTRWM_X_QRUN64_L(W, E, M) quad_f64_entry<QTGT<W, quad_min_own(W, E)>, QLaplace<W, quad_min_own(W, E)>, W, E, M>(),
+#define PTRWM_X_QRUN64_U(W, E, M) quad_f64_entry<QTGT<W, quad_min_own(W, E)>, QUniformRadius<W, quad_min_own(W, E)>, W, E, M>(),
 // One translation unit per target (csrc/quad_<target>.hip) defines its table with this macro.
 #define PTRWM_DEFINE_QUAD_VARIANTS(SYMBOL, QTARGET)                        \
   template <int W, int M>                                                  \
@@ -216,7 +227,10 @@ hipError_t launch_run_quad(const KArgs &a, unsigned grid, bool full, hipStream_t
   const QuadVariants &SYMBOL##_quad() {                                    \
     static const QuadVariants v = {{{PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN_N)},   \
                                     {PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN_L)},   \
-                                    {PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN_U)}}}; \
+                                    {PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN_U)}},  \
+                                   {{PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN64_N)}, \
+                                    {PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN64_L)}, \
+                                    {PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN64_U)}}}; \
     return v;                                                              \
   }
 

@@ -110,6 +110,8 @@ class RunArgs(C.Structure):
         ("trace_every", C.c_int32),
         ("trace_row0", C.c_int64),
         ("accept_flags", C.c_void_p),
+        ("state_f64", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -366,7 +368,7 @@ class RunPlan:
         target: Target,
         proposal: Proposal,
         *,
-        state: torch.Tensor,  # [C, T, D] float32
+        state: torch.Tensor,  # [C, T, D] float32, or float64 (state_f64 of include/ptrwm.h: the reference's dtype=float64)
         logp: torch.Tensor,  # [C, T] float32
         beta: torch.Tensor,  # [T] float32
         burn_in: int = 0,
@@ -381,6 +383,9 @@ class RunPlan:
         last_swap_ordinal: Optional[torch.Tensor] = None,  # [C, T] int64
     ):
         self._lib = load_library()
+        if isinstance(state, torch.Tensor) and state.dtype not in (torch.float32, torch.float64):
+            raise TypeError(f"state must be torch.float32 or torch.float64, got {state.dtype}")
+        self.state_dtype = state.dtype if isinstance(state, torch.Tensor) else torch.float32
         if state.dim() != 3:
             raise ValueError("state must be [n_chains, n_temps, dim]")
         Cn, T, D = state.shape
@@ -399,7 +404,8 @@ class RunPlan:
         a.n_temps = T
         a.n_chains = Cn
         a.chain_offset = chain_offset
-        a.state = _require_device(state, "state", torch.float32)
+        a.state = _require_device(state, "state", self.state_dtype)
+        a.state_f64 = 1 if self.state_dtype == torch.float64 else 0
         a.logp = _require_device(logp, "logp", torch.float32)
         a.beta = _require_device(beta, "beta", torch.float32)
         for name, t, dt in (
@@ -463,7 +469,7 @@ class RunPlan:
         elif not (plain and self._plain):
             self._last_trace = (None, None, None)
             Cn, T, D = self.shape
-            a.ext_prop = _opt(ext_prop, "ext_prop", torch.float32)
+            a.ext_prop = _opt(ext_prop, "ext_prop", self.state_dtype)  # (the state's dtype: double normals for double states)
             a.ext_u = _opt(ext_u, "ext_u", torch.float32)
             a.ext_swap_u = _opt(ext_swap_u, "ext_swap_u", torch.float32)
             if ext_prop is not None:
@@ -471,7 +477,7 @@ class RunPlan:
                 if (tuple(ext_prop.shape) != (n_steps, Cn, T, raw) or ext_u is None
                         or tuple(ext_u.shape) != (n_steps, Cn, T)):
                     raise ValueError("ext_prop/ext_u shapes do not match [n_steps, n_chains, n_temps, raw]")
-            a.trace = _opt(trace, "trace", torch.float32)
+            a.trace = _opt(trace, "trace", self.state_dtype)
             a.trace_logp = _opt(trace_logp, "trace_logp", torch.float32)
             a.trace_every, a.trace_chains, a.trace_temps = 0, 0, 0
             if trace is not None:
@@ -508,6 +514,8 @@ class RunPlan:
         passes the result to ``split_accept``."""
         a = self._a
         Cn, T, D = self.shape
+        if self.state_dtype != torch.float32:
+            raise TypeError("split steps take float32 states (float64 states: the fused kernel only)")
         props, acc_u = self._split_buffers()
         a.step0 = step
         self._last_trace = (None, None, None)
@@ -558,6 +566,8 @@ class RunPlan:
         (stream 1 = the stream the fused kernel's own swap events use)."""
         a = self._a
         Cn, T, D = self.shape
+        if self.state_dtype != torch.float32:
+            raise TypeError("the stand-alone swap sweep takes float32 states (float64 states: the fused kernel only)")
         if ext_swap_u is not None and tuple(ext_swap_u.shape) != (Cn, T - 1):
             raise ValueError(f"ext_swap_u must be [{Cn}, {T - 1}]")
         a.step0 = rng_step
@@ -574,7 +584,7 @@ def run(
     target: Target,
     proposal: Proposal,
     *,
-    state: torch.Tensor,  # [C, T, D] float32
+    state: torch.Tensor,  # [C, T, D] float32 (or float64: states, trace and ext_prop in double, include/ptrwm.h state_f64)
     logp: torch.Tensor,  # [C, T] float32
     beta: torch.Tensor,  # [T] float32
     step0: int,

@@ -258,32 +258,39 @@ def gen_rwm(T):
 # ------------------------------------------------------------------------------------------------
 # PT trajectories (torch class on CPU; the reference's swap is the Q1 row copy, sequential order)
 # ------------------------------------------------------------------------------------------------
-def gen_pt(T):
+def gen_pt(T, only=None):
     print("PT trajectory fixtures")
     geo8 = [1.0, 0.5, 0.25, 0.125, 0.0625, 0.03125, 0.015625, 0.01]
-    cases = [  # (fixture, target key, var, ladder, swap_every, N, burn_in, seed)
+    cases = [  # (fixture, target key, var, ladder, swap_every, N, burn_in, seed[, dtype])
         ("pt_rc15_geo8", "rc15_d30", 2.38**2 / 30, geo8, 10, 400, 50, 142),
+        # the same run with dtype=torch.float64 (experiment_pt_GPU.py:236 --use_double_precision): states, increments and
+        # the Cholesky factors in double; the log-densities come out double too (type promotion in log_density)
+        ("pt_rc15_geo8_f64", "rc15_d30", 2.38**2 / 30, geo8, 10, 400, 50, 147, torch.float64),
         ("pt_rc5_fine12", "rc5_d30", 2.38**2 / 30, [float(0.05 ** (i / 11)) for i in range(12)], 5, 300, 20, 143),
         ("pt_tm15_t32", "tm15_d30", 2.38**2 / 30, [float(0.01 ** (i / 31)) for i in range(32)], 10, 150, 0, 144),
         ("pt_even_t5", "even_d30", 0.01, [1.0, 0.7, 0.45, 0.3, 0.2], 3, 300, 31, 145),
         ("pt_hyb_t4", "hyb_5_4", 0.02, [1.0, 0.6, 0.35, 0.2], 4, 300, 10, 146),
     ]
-    for name, tkey, var, ladder, se, N, burn, seed in cases:
+    for name, tkey, var, ladder, se, N, burn, seed, *rest in cases:
+        dtype = rest[0] if rest else torch.float32
+        if only is not None and name not in only:
+            continue
         t = T[tkey]
         D, Tn = t.dim, len(ladder)
         total = burn + N
         np.random.seed(seed)
         alg = quiet(ref_alg.ParallelTemperingRWM_GPU_Optimized, D, var, t, True, beta_ladder=ladder, swap_every=se,
-                    burn_in=burn, device="cpu", pre_allocate_steps=N)
+                    burn_in=burn, device="cpu", pre_allocate_steps=N, dtype=dtype)
         x0 = alg.current_states[0].numpy().copy()
         # the random tensors generate_samples draws, in its order (pt_rwm_gpu_optimized.py:710-723)
         torch.manual_seed(seed)
         max_swaps = total // se * (Tn - 1) + 100
         swap_r = torch.rand(max_swaps + 100)
         mh_u = torch.rand(total + 10, Tn)
-        z = torch.randn(total + 10, Tn, D)
+        z = torch.randn(total + 10, Tn, D, dtype=dtype)
         torch.manual_seed(seed)
         cold = quiet(alg.generate_samples, N)
+        assert alg.current_states.dtype == dtype and cold.dtype == dtype
         chains = alg.pre_allocated_chains.numpy()  # [T, total+1, D]
         logps = alg.pre_allocated_log_densities.numpy()  # [T, total+1]
         assert cold.shape == (N, D)
@@ -425,6 +432,8 @@ if __name__ == "__main__":
         gen_rwm(T)
     if "pt" in which:
         gen_pt(T)
+    if "pt_f64" in which:  # only the float64 trajectory (the other fixtures are left untouched)
+        gen_pt(T, only={"pt_rc15_geo8_f64"})
     if "sweep" in which:
         gen_sweep(T)
     if "superfunnel" in which:

@@ -259,9 +259,16 @@ def step_log_ratios(spec, prop, pre_state, ext_row, beta):
     """fp64 log accept ratios beta_t (l(y_t) - l(x_t)) of ONE ladder for one step, and the pieces a proof needs.
     pre_state [T, D] float32 (the last agreed state), ext_row [T, raw] the step's raw proposal randoms."""
     T, D = pre_state.shape
-    inc = O.propose(prop.oracle(), D, 1, ext_raw=np.ascontiguousarray(ext_row, dtype=f32)[None])[0]  # fp32 arithmetic
-    x = np.ascontiguousarray(pre_state, dtype=f32)
-    y = (x + inc.astype(f32)).astype(f32)
+    if np.asarray(pre_state).dtype == np.float64:
+        # state_f64 mode (Normal proposal): y = x + scale * z, one double product and one double sum, as the reference's
+        # dtype=torch.float64 path and the kernel's F64 form compute it
+        assert prop.kind == O.PROPOSAL_NORMAL
+        x = np.ascontiguousarray(pre_state, dtype=np.float64)
+        y = x + np.asarray(ext_row, np.float64) * np.asarray(prop.temp_scale, f32).astype(np.float64)[:, None]
+    else:
+        inc = O.propose(prop.oracle(), D, 1, ext_raw=np.ascontiguousarray(ext_row, dtype=f32)[None])[0]  # fp32 arithmetic
+        x = np.ascontiguousarray(pre_state, dtype=f32)
+        y = (x + inc.astype(f32)).astype(f32)
     l_x = O.logdensity(spec.oracle(), x, "f64")
     l_y = O.logdensity(spec.oracle(), y, "f64")
     with np.errstate(invalid="ignore"):
@@ -344,7 +351,7 @@ def check_parity(run_a, run_b, spec, prop, *, state, logp, beta, n_steps, burn_i
     ladder is restarted, so an engine that draws its randoms from (seed, step, chain) stays on its stream.
     Returns the list of proven flips [(global step, ladder, kind, margin in tolerance bands)]."""
     flips = [] if _flips is None else _flips
-    state = np.ascontiguousarray(state, dtype=f32)
+    state = np.ascontiguousarray(state, dtype=np.float64 if np.asarray(state).dtype == np.float64 else f32)  # f64: state_f64 mode
     Cn, T, D = state.shape
     logp = np.ascontiguousarray(logp, dtype=f32).reshape(Cn, T)
     beta = np.asarray(beta, dtype=f32)
@@ -467,7 +474,8 @@ def gpu_run(spec, prop, device, *, state, logp, beta, n_steps, trace_temps=0, wa
     import ptrwm_hip as E
 
     Cn, T, D = state.shape
-    st, lp = dev_t(state, device), dev_t(logp, device).reshape(Cn, T).contiguous()
+    sdt = torch.float64 if np.asarray(state).dtype == np.float64 else torch.float32  # float64: the engine's state_f64 mode
+    st, lp = dev_t(state, device, sdt), dev_t(logp, device).reshape(Cn, T).contiguous()
     res = {
         "n_accept": torch.zeros(Cn, T, dtype=torch.int64, device=device),
         "sq_jump": torch.zeros(Cn, T, dtype=torch.float64, device=device),
@@ -476,14 +484,14 @@ def gpu_run(spec, prop, device, *, state, logp, beta, n_steps, trace_temps=0, wa
     }
     trace = trace_logp = flags = None
     if trace_temps:
-        trace = torch.zeros(n_steps, Cn, trace_temps, D, device=device)
+        trace = torch.zeros(n_steps, Cn, trace_temps, D, device=device, dtype=sdt)
         trace_logp = torch.zeros(n_steps, Cn, trace_temps, device=device)
     if want_flags:
         flags = torch.zeros(n_steps, Cn, T, dtype=torch.uint8, device=device)
     E.run(spec.engine(device), prop.engine(device), state=st, logp=lp, beta=dev_t(beta, device), n_steps=n_steps,
           n_accept=res["n_accept"], sq_jump=res["sq_jump"], swap_accept=res["swap_accept"],
           last_swap_ordinal=res["last_swap_ordinal"], trace=trace, trace_logp=trace_logp, accept_flags=flags,
-          ext_prop=None if ext_prop is None else dev_t(ext_prop, device),
+          ext_prop=None if ext_prop is None else dev_t(ext_prop, device, sdt),
           ext_u=None if ext_u is None else dev_t(ext_u, device),
           ext_swap_u=None if ext_swap_u is None else dev_t(ext_swap_u, device), **kw)
     torch.cuda.synchronize()
@@ -525,11 +533,17 @@ def check_parity_philox(run, spec, prop, *, state, logp, beta, n_steps, burn_in,
     ulp (hardware sin / cos / log against libm), so states are compared with a tolerance (`exact_states=False`) and, if
     `segment` is given, both engines restart from the oracle's own trajectory every `segment` steps so that rounding
     drift cannot build up over a long horizon.  Returns the proven flips."""
-    state = np.ascontiguousarray(state, dtype=f32)
+    f64 = np.asarray(state).dtype == np.float64  # the engine's state_f64 mode
+    state = np.ascontiguousarray(state, dtype=np.float64 if f64 else f32)
     Cn, T, D = state.shape
     logp = np.ascontiguousarray(logp, dtype=f32).reshape(Cn, T)
     ext_prop, ext_u, ext_swap_u = O.philox_randoms(prop.kind, D, T, Cn, seed=seed, step0=step0, n_steps=n_steps,
                                                    burn_in=burn_in, swap_every=swap_every, chain_offset=chain_offset)
+    if f64:
+        # the kernel adds its float increment to the double state; the oracle's double path multiplies the same float
+        # normal by the float scale in double: equal to ~1e-8 of the increment, compared with the usual state tolerance
+        assert prop.kind == O.PROPOSAL_NORMAL, "state_f64 comparisons against the oracle: Normal proposal"
+        ext_prop = ext_prop.astype(np.float64)
     run_a, run_b = philox_runner(run, seed), oracle_runner(spec, prop)
     common = dict(beta=beta, burn_in=burn_in, swap_every=swap_every, swap_mode=swap_mode, swap_order=swap_order,
                   chain_offset=chain_offset, exact_states=False, **tol)
@@ -582,7 +596,10 @@ def check_production_run(run, x0, n_cmp, segment=50):
     device = run.device
     spec, prop = spec_from_engine(run.target), prop_from_engine(run.proposal)
     T, D = run.n_temps, run.dim
-    state = np.broadcast_to(np.asarray(x0, f32), (n_cmp, T, D)).copy()
+    import torch
+
+    sdt = np.float64 if getattr(run, "dtype", torch.float32) == torch.float64 else f32
+    state = np.broadcast_to(np.asarray(x0, sdt), (n_cmp, T, D)).copy()
     logp = E.logdensity(run.target, dev_t(state.reshape(-1, D), device)).cpu().numpy().reshape(n_cmp, T)
     kw = dict(state=state, logp=logp, beta=run.beta.cpu().numpy(), n_steps=run.steps_done, burn_in=run.burn_in,
               swap_every=run.swap_every, swap_mode=run.swap_mode, swap_order=run.swap_order, chain_offset=run.chain_offset)

@@ -307,8 +307,9 @@ def test_the_two_gpu_drivers_calls_and_reads(device):
                 beta_ladder=None, swap_acceptance_rate=target_swap_rate, iterative_temp_spacing=True,
                 N_samples_swap_est=2000, iterative_tolerance=0.01, iterative_max_pn_steps=50, iterative_fail_tol_factor=3.0,
                 dtype=torch.float64)
-        # `use_double_precision` callers are TOLD that states are computed and stored in float32 (not a silent change)
-        assert any("float32" in str(x.message) for x in w)
+        # `use_double_precision` (experiment_pt_GPU.py:236) is honoured: states and chains in double, no dtype warning
+        assert not any("float32" in str(x.message) for x in w)
+        assert sim.algorithm.dtype == torch.float64
         chain = sim.generate_samples(progress_bar=False)
         assert isinstance(chain, list) and len(chain) == n and len(chain[0]) == dim
         alg = sim.algorithm
@@ -318,9 +319,12 @@ def test_the_two_gpu_drivers_calls_and_reads(device):
         pt_esjds.append(sim.pt_expected_squared_jump_distance())
         times.append(0.1)
         assert isinstance(pt_rates[-1], float) and 0.0 <= pt_rates[-1] <= 1.0 and pt_esjds[-1] >= 0.0
+        assert alg.get_cold_chain_gpu().dtype == torch.float64 and alg.current_states.dtype == torch.float64
+        assert alg.current_log_densities.dtype == torch.float32  # as the reference allocates them (:436-442)
         cold = alg.get_cold_chain_gpu().cpu().numpy()
         assert cold.shape == (n + burn + 1, dim)
-        assert np.array_equal(cold[1 + burn:], np.asarray(chain, dtype=np.float32))
+        assert np.array_equal(cold[1 + burn:], np.asarray(chain, dtype=np.float64))
+        assert np.any(cold != cold.astype(np.float32))  # genuinely double: the low bits of the sums are kept
         assert len(alg.chain) == n + burn + 1  # the lazy list form the fallback branch of the driver reads
         assert alg.num_swap_attempts == (n + burn) // alg.swap_every * (alg.num_chains - 1) - burn // alg.swap_every * (alg.num_chains - 1)
     data = {"target_distribution": target.get_name(), "dimension": dim, "num_iterations": n, "seed": 1, "total_time": 0.2,
@@ -1052,3 +1056,28 @@ def test_the_example_scripts_run(device):
     assert out.returncode == 0, out.stdout + out.stderr
     m = re.search(r"mean radius ([0-9.]+)", out.stdout)
     assert m and abs(float(m.group(1)) - 4.0) < 0.25, out.stdout
+
+
+def test_pt_class_with_float64_states(device):
+    """ParallelTemperingRWM_GPU_Optimized(dtype=torch.float64) (experiment_pt_GPU.py:236 --use_double_precision): states,
+    stored chains and the returned samples are double, log-densities float32 (pt_rwm_gpu_optimized.py:431-449); the run
+    follows the oracle's double path on the same Philox stream decision for decision (production run == traced twin bit
+    for bit, every differing decision proven), and the float32 class on the same seed makes the same decisions."""
+    dim, C, N, burn = 30, 16, 120, 20
+    target = RoughCarpetDistributionTorch(dim, device=device, mode_centers=[-15.0, 0.0, 15.0])
+
+    def make(dtype):
+        return ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target, geom_temp_spacing=True, swap_every=5, burn_in=burn,
+                                                  device=device, num_replicas=C, seed=31, trace="cold", pre_allocate_steps=N,
+                                                  dtype=dtype)
+    a = make(torch.float64)
+    cold = a.generate_samples(N)
+    assert cold.dtype == torch.float64 and cold.shape == (N, dim) and a.current_states.dtype == torch.float64
+    assert a.pre_allocated_chains.dtype == torch.float64 and a.pre_allocated_log_densities.dtype == torch.float32
+    assert a.expected_squared_jump_distance_gpu() > 0 and 0 < a.swap_acceptance_rate < 1
+    H.check_production_run(a._run, np.zeros(dim), C)
+    b = make(torch.float32)
+    b.generate_samples(N)
+    same = (a._run.n_accept == b._run.n_accept).float().mean().item()
+    assert same > 0.95  # the two precisions part only where a decision sits on its threshold
+    assert torch.allclose(a._run.state.float(), b._run.state, atol=1e-2) or same < 1.0

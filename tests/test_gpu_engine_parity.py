@@ -844,3 +844,113 @@ def test_philox_stream_quality_on_the_run_layout(device):
     assert corr(z[..., 0::2] ** 2, z[..., 1::2] ** 2) < lim(z[..., 0::2].size)  # the two outputs of a pair, second moments
     assert corr(u, z[..., 0]) < lim(u.size) and corr(u, z[..., -1]) < lim(u.size)  # accept uniform vs its step's normals
     assert corr(u[:, :-1], u[:, 1:]) < lim(u[:, 1:].size)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# state_f64 (include/ptrwm.h): the reference's dtype=torch.float64 (pt_rwm_gpu_optimized.py:134,431-449)
+# ---------------------------------------------------------------------------------------------------------
+def test_float64_golden_trajectory(device):
+    """tests/golden/pt_rc15_geo8_f64.npz: the reference's PT sampler run with dtype=torch.float64 (RoughCarpet d=30, its
+    geometric 8-rung ladder, 450 steps), with the double normals and float uniforms it consumed.  The kernel's F64 form,
+    fed the same arrays, must reproduce the reference's double states BIT FOR BIT at every temperature and step up to
+    a Metropolis / swap decision that differs - and such a decision must be a proven fp32-level flip (the reference
+    evaluates the density of its double states in double, the kernel on the state rounded to float)."""
+    f = H.load("pt_rc15_geo8_f64.npz")
+    spec = H.target_spec(str(f["target_key"]))
+    ladder = f["beta_ladder"]
+    T, D = len(ladder), spec.dim
+    burn, N, se = int(f["burn_in"]), int(f["n_samples"]), int(f["swap_every"])
+    total = burn + N
+    assert f["chains"].dtype == np.float64 and f["ext_prop"].dtype == np.float64
+    prop = H.proposal_spec("Normal", D, ladder, base_variance_scalar=float(f["var"]))
+    x0 = np.broadcast_to(f["x0"], (1, T, D)).astype(np.float64).copy()
+    lp0 = O.logdensity(spec.oracle(), x0.reshape(-1, D), "f64").astype(np.float32).reshape(1, T)
+    kw = dict(state=x0, logp=lp0, beta=ladder.astype(np.float32), n_steps=total, burn_in=burn, swap_every=se,
+              ext_prop=np.ascontiguousarray(f["ext_prop"][:, None]), ext_u=np.ascontiguousarray(f["ext_u"][:, None]),
+              ext_swap_u=np.ascontiguousarray(f["ext_swap_u"][:, None]), swap_mode=E.SWAP_REFERENCE_COPY)
+    chains = f["chains"].transpose(1, 0, 2)  # [step, T, D], row 0 = the initial state
+    # the oracle's double instantiation is the reference's trajectory, bit for bit ...
+    want = H.oracle_runner(spec, prop)(step0=0, **kw)
+    assert want["trace"].dtype == np.float64 and np.array_equal(want["trace"][:, 0], chains[1:])
+    assert int(want["swap_accept"].sum()) == int(f["num_swap_acceptances"])
+    # ... and the kernel follows it: double states identical, any differing decision proven
+    flips = H.check_parity(gpu_runner(spec, prop, device), H.oracle_runner(spec, prop), spec, prop, exact_states=True, **kw)
+    got = gpu_runner(spec, prop, device)(step0=0, **kw)
+    assert got["trace"].dtype == np.float64
+    if not flips:
+        assert np.array_equal(got["trace"][:, 0], chains[1:])
+        assert int(got["swap_accept"].sum()) == int(f["num_swap_acceptances"])
+        esjd = got["sq_jump"][0, 0] / N
+        assert esjd == pytest.approx(float(f["esjd"]), rel=1e-12)
+    logp_close(got["trace_logp"][:, 0], f["logp_chains"].T[1:], extra_abs=3e-4)
+
+
+F64_CASES = [("rc15_d30", 8, 5), ("tm_d50", 20, 3), ("even_d30", 3, 11), ("gamma_d5", 1, 40), ("hyb_5_4", 70, 2)]
+
+
+@pytest.mark.parametrize("tkey,T,Cn", F64_CASES, ids=[f"{c[0]}-T{c[1]}" for c in F64_CASES])
+def test_float64_states_vs_oracle(device, tkey, T, Cn):
+    """The F64 form on other targets, ladder shapes (one temperature, a wavefront's worth, wider than a wavefront) and
+    every swap semantics: external double normals (states bit-identical to the oracle's double path between proven flips)
+    and the in-kernel Philox stream (every differing decision proven)."""
+    spec = H.target_spec(tkey)
+    rng = np.random.default_rng(zlib.crc32(f"f64-{tkey}-{T}".encode()))
+    beta = (0.05 ** (np.arange(T) / max(1, T - 1))).astype(np.float32)
+    scale = 0.01 if "Rosenbrock" in spec.cls else (0.3 if "Gamma" in spec.cls else 2.38**2 / spec.dim)
+    prop = H.proposal_spec("Normal", spec.dim, beta, base_variance_scalar=scale)
+    st32, lp = start_state(spec, Cn, T, rng)
+    st = st32.astype(np.float64) + 1e-9 * rng.standard_normal(st32.shape)  # genuinely double starting points
+    lp = O.logdensity(spec.oracle(), st.reshape(-1, spec.dim), "f64").astype(np.float32).reshape(Cn, T)
+    N, burn, se = 60, 7, 4
+    n_ev = H.events_upto(N, se, burn)
+    for mode, order in (("exchange", "sequential"), ("reference_copy", "even_odd")):
+        kw = dict(state=st, logp=lp, beta=beta, n_steps=N, burn_in=burn, swap_every=se, swap_mode=E.SWAP_MODES[mode],
+                  swap_order=E.SWAP_ORDERS[order])
+        H.check_parity(gpu_runner(spec, prop, device), H.oracle_runner(spec, prop), spec, prop, exact_states=True,
+                       ext_prop=rng.standard_normal((N, Cn, T, spec.dim)), ext_u=rng.random((N, Cn, T)).astype(np.float32),
+                       ext_swap_u=rng.random((n_ev, Cn, T - 1)).astype(np.float32) if T > 1 else None, **kw)
+        H.check_parity_philox(gpu_runner(spec, prop, device), spec, prop, seed=77, chain_offset=5, segment=PHILOX_SEGMENT, **kw)
+
+
+def test_float64_states_keep_increments_a_float_state_loses(device):
+    """What dtype=float64 is for: far from the origin a float state cannot represent x + increment (half an ulp of
+    3e4 is 1e-3, the increments here are ~1e-4): the float run accepts moves that leave the state where it was, the double
+    run carries them.  Same seed, same Philox stream, same target (a unit Gaussian centred at 3e4)."""
+    dim, Cn, N = 8, 64, 200
+    mean = np.full(dim, 3.0e4, np.float32)
+    spec = H.TargetSpec(O.TARGET_DIAG_GAUSSIAN, dim, (np.float32(-0.5 * dim * np.log(2 * np.pi)),), (0,), mean, np.ones(dim, np.float32))
+    prop = H.proposal_spec("Normal", dim, [1.0], base_variance_scalar=1e-8, single=True)
+    st = np.broadcast_to(mean.astype(np.float64), (Cn, 1, dim)).copy()
+    lp = O.logdensity(spec.oracle(), st.reshape(-1, dim), "f64").astype(np.float32).reshape(Cn, 1)
+    kw = dict(logp=lp, beta=np.float32([1.0]), step0=0, n_steps=N, burn_in=0, swap_every=1, seed=9)
+    g32 = gpu_run(spec, prop, device, state=st.astype(np.float32), **kw)
+    g64 = gpu_run(spec, prop, device, state=st, **kw)
+    assert g32["state"].dtype == np.float32 and g64["state"].dtype == np.float64
+    assert g32["n_accept"].sum() > 0.9 * Cn * N and g64["n_accept"].sum() > 0.9 * Cn * N  # tiny moves: nearly all accepted
+    assert np.array_equal(g32["state"], st.astype(np.float32)) and g32["sq_jump"].sum() == 0.0  # ... and all of them lost
+    moved = np.abs(g64["state"] - st)
+    assert moved.min() > 0 and 1e-4 < np.sqrt((moved**2).mean()) < 1e-2  # a random walk of 200 steps of 1e-4
+    assert g64["sq_jump"].sum() / (Cn * N) == pytest.approx(dim * 1e-8, rel=0.1)
+
+
+def test_float64_argument_validation(device):
+    spec = H.target_spec("rc15_d30")
+    st = torch.zeros(2, 1, 30, device=device, dtype=torch.float64)
+    lp = torch.zeros(2, 1, device=device)
+    b = torch.ones(1, device=device)
+    lap = H.proposal_spec("Laplace", 30, [1.0], base_variance_vector=np.full(30, 0.1), single=True)
+    with pytest.raises(E.PTRWMError) as ei:  # external randoms in double: the Normal proposal only
+        E.run(spec.engine(device), lap.engine(device), state=st, logp=lp, beta=b, step0=0, n_steps=1,
+              ext_prop=torch.zeros(1, 2, 1, 30, device=device, dtype=torch.float64), ext_u=torch.zeros(1, 2, 1, device=device))
+    assert ei.value.code == -5
+    with pytest.raises(TypeError):  # a float trace for double states
+        E.run(spec.engine(device), lap.engine(device), state=st, logp=lp, beta=b, step0=0, n_steps=1,
+              trace=torch.zeros(1, 2, 1, 30, device=device))
+    plan = E.RunPlan(spec.engine(device), lap.engine(device), state=st, logp=lp, beta=b)
+    with pytest.raises(TypeError, match="float32 states"):
+        plan.swap_sweep(0, 0)
+    with pytest.raises(TypeError, match="float32 or torch.float64"):
+        E.RunPlan(spec.engine(device), lap.engine(device), state=st.half(), logp=lp, beta=b)
+    E.run(spec.engine(device), lap.engine(device), state=st, logp=lp, beta=b, step0=0, n_steps=3, seed=1)  # Philox: any proposal
+    torch.cuda.synchronize()
+    assert st.dtype == torch.float64 and bool(torch.isfinite(st).all())

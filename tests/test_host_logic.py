@@ -246,8 +246,17 @@ def test_pt_constructor_contract_and_ladders():
     c = ParallelTemperingRWM_GPU_Optimized(6, 0.3, t, beta_ladder=[0.99**i for i in range(257)], device="cpu")
     with pytest.raises(ValueError, match="one workgroup"):
         c.step()
-    with pytest.warns(UserWarning, match="float32"):
-        ParallelTemperingRWM_GPU_Optimized(6, 0.3, t, beta_ladder=[1.0, 0.5], device="cpu", dtype=torch.float64)
+    # dtype=torch.float64 is honoured (states, chains, increments in double: the engine's state_f64 mode), no warning;
+    # anything else is refused
+    import warnings as _w
+    with _w.catch_warnings():
+        _w.simplefilter("error")
+        d = ParallelTemperingRWM_GPU_Optimized(6, 0.3, t, beta_ladder=[1.0, 0.5], device="cpu", dtype=torch.float64,
+                                               pre_allocate_steps=4)
+    assert d.dtype == torch.float64 and d.pre_allocated_chains.dtype == torch.float64
+    assert d.pre_allocated_log_densities.dtype == torch.float32 and d.beta_tensor.dtype == torch.float32
+    with pytest.raises(TypeError, match="float32 or torch.float64"):
+        ParallelTemperingRWM_GPU_Optimized(6, 0.3, t, beta_ladder=[1.0, 0.5], device="cpu", dtype=torch.float16)
 
 
 def test_harness_dispatch_and_proposal_factory():
