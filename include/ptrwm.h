@@ -151,6 +151,9 @@ int32_t ptrwm_has_quad_variant(int32_t target_kind, int32_t proposal_kind, int32
 /* 1 if ptrwm_run has a one-thread-per-replica variant for (target, proposal, dim), else 0 (never above dim 64).  Where it
  * returns 0 PTRWM_FORM_THREAD runs the lane-split kernel: a comparison of the two forms is vacuous there. */
 int32_t ptrwm_has_thread_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim);
+/* The form PTRWM_FORM_AUTO runs for a float-state launch of this shape on the current device (PTRWM_FORM_THREAD or
+ * PTRWM_FORM_QUAD), or a negative status.  Introspection only: the forms give the same bits. */
+int32_t ptrwm_auto_form(int32_t target_kind, int32_t proposal_kind, int32_t dim, int32_t n_temps, int64_t n_chains);
 
 /* Number of raw random numbers one MH proposal consumes from `ext_prop`
  * (NORMAL: dim normals; LAPLACE: dim uniforms in [0,1); UNIFORM_RADIUS: dim

@@ -19,19 +19,71 @@ struct VariantPair {
 
 // ---- which form of the step kernel runs (quad.h) ------------------------------------------------------------------
 // The two forms are bit-identical on the same Philox stream, so this is a speed decision only; ptrwm_set_kernel_form()
-// pins it for tests and tuning.  AUTO follows the measured crossover (profiles/r02_form_sweep.txt, both forms timed over
-// batch sizes, ladder lengths and dims on one MI355X).  w = wavefronts per SIMD the one-thread-per-replica kernel would
-// launch:
-//   dim < 16         never (profiles/r02_single_ladder.txt)
-//   16 <= dim <= 32  lane-split when w < 1.6 (ladders of <= 16 temperatures) or w < 1.0 (longer ladders): a lone wave
-//                    issues one VALU instruction per ~5 cycles instead of ~3.4, and below one wave per SIMD the split
-//                    puts four times as many SIMDs to work (2.5-3.2x for a single ladder)
-//   32 < dim <= 64   the four lanes own 16 dims each, so dims well below 64 waste lanes (dim 50: 28 %): lane-split when
-//                    w < 0.75, or w < 2 for dim >= 57 (two waves of the 64-wide thread kernel per SIMD: quad is 9-25 %
-//                    faster below that); at full batches the thread kernel is 4-30 % faster at every dim of the class
-//   dim > 64         lane-split always: it is the only form there (the one-thread-per-replica kernel needed 340-420
-//                    VGPRs - one wave per SIMD, 8-25 % slower at full batches, 1.8x at small ones - and sat in the
-//                    register regime in which hipcc miscompiled it twice; see variants.h)
+// pins it for tests and tuning.  AUTO compares a model of both forms' throughput at the launch's size
+// (tools/form_fit.py, fitted to profiles/r03_form_sweep_dense.txt - both forms timed over waves per SIMD, ladder lengths
+// and dims on one MI355X - and checked on a held-out sweep, profiles/r03_form_sweep_heldout.txt).  With w = wavefronts
+// per SIMD the one-thread-per-replica form would launch:
+//   thread form   rate = A(k) w / k, k = ceil(w): a launch lasts as long as its fullest SIMDs, so at w = 1.25 the form
+//                 runs at 0.625 of its two-waves rate, not at its one-wave rate (the dips of profiles/r02_form_sweep.txt)
+//   lane-split    four times the waves with a quarter of the work each: its saw-tooth is four times finer and lives in
+//                 the measured curve Q(w)
+//   dim < 16      never lane-split (a lane would own <= 3 dims: profiles/r02_single_ladder.txt)
+//   dim > 64      always: it is the only form there (the one-thread-per-replica kernel needed 340-420 VGPRs and sat in
+//                 the register regime in which hipcc miscompiled it twice; see variants.h)
+//   w > 4         never (the thread form is saturated; the lane-split form repeats the per-replica scalar work)
+#include "form_table.inc"
+
+static void form_lerp(const float *a, const float *b, float t, float *out, int n) {
+  for (int i = 0; i < n; ++i) out[i] = a[i] + (b[i] - a[i]) * t;
+}
+
+// interpolated model parameters at (dim, n_temps): dims within the lane-width class of `dim`, ladder lengths in log2
+static void form_params(int dim, int n_temps, float *thread4, float *quad) {
+  int d0 = -1, d1 = -1;  // last grid dim <= dim and first grid dim >= dim, within dim's lane-width class
+  for (int i = 0; i < kFormND; ++i) {
+    if ((kFormDims[i] <= 32) != (dim <= 32)) continue;
+    if (kFormDims[i] <= dim) d0 = i;
+    if (kFormDims[i] >= dim && d1 < 0) d1 = i;
+  }
+  if (d0 < 0) d0 = d1;  // below the class's first grid dim: clamp
+  if (d1 < 0) d1 = d0;  // above its last
+  const float td = d0 == d1 ? 0.0f : (float)(dim - kFormDims[d0]) / (float)(kFormDims[d1] - kFormDims[d0]);
+  int t0 = 0, t1 = kFormNT - 1;
+  for (int i = 0; i < kFormNT; ++i) {
+    if (kFormTemps[i] <= n_temps) t0 = i;
+    if (kFormTemps[i] >= n_temps) { t1 = i; break; }
+  }
+  if (t1 < t0) t1 = t0;
+  const float tt = t0 == t1 ? 0.0f
+                            : (float)((__builtin_log2((double)n_temps) - __builtin_log2((double)kFormTemps[t0])) /
+                                      (__builtin_log2((double)kFormTemps[t1]) - __builtin_log2((double)kFormTemps[t0])));
+  float lo[kFormNW], hi[kFormNW];
+  form_lerp(kFormThread[d0][t0], kFormThread[d1][t0], td, lo, 4);
+  form_lerp(kFormThread[d0][t1], kFormThread[d1][t1], td, hi, 4);
+  form_lerp(lo, hi, tt, thread4, 4);
+  form_lerp(kFormQuad[d0][t0], kFormQuad[d1][t0], td, lo, kFormNW);
+  form_lerp(kFormQuad[d0][t1], kFormQuad[d1][t1], td, hi, kFormNW);
+  form_lerp(lo, hi, tt, quad, kFormNW);
+}
+
+static bool lane_split_is_faster(int dim, int n_temps, double w) {
+  if (dim < 16 || w > kFormW[kFormNW - 1]) return false;
+  float a[4], q[kFormNW];
+  form_params(dim, n_temps, a, q);
+  int k = (int)__builtin_ceil(w - 1e-9);
+  if (k < 1) k = 1;
+  const double thread = a[k - 1] * w / k;
+  double quad;
+  if (w <= kFormW[0]) {
+    quad = q[0] * w / kFormW[0];
+  } else {
+    int i = 0;
+    while (i + 2 < kFormNW && kFormW[i + 1] <= w) ++i;
+    quad = q[i] + (q[i + 1] - q[i]) * (w - kFormW[i]) / (kFormW[i + 1] - kFormW[i]);
+  }
+  return quad > thread;
+}
+
 static int g_kernel_form = PTRWM_FORM_AUTO;  // read / written with __atomic builtins (ptrwm_set_kernel_form may race with a launch)
 
 // SIMDs of the current device (compute units x 4), asked once per device: the form rule is stated in wavefronts per SIMD,
@@ -50,6 +102,14 @@ static long long device_simds() {
   }
   return n;
 }
+
+// AUTO's choice for a launch of n_chains ladders where both forms exist
+static bool auto_prefers_lane_split(int dim, int n_temps, long long n_chains) {
+  const long long cpw1 = n_temps > 64 ? 1 : 64 / n_temps;
+  const long long waves1 = n_temps > 64 ? n_chains * ((n_temps + 63) / 64) : (n_chains + cpw1 - 1) / cpw1;
+  return lane_split_is_faster(dim, n_temps, (double)waves1 / (double)device_simds());
+}
+
 
 // alt: the specialised functor of the kind - RoughCarpet2 (the host proved the third mixture term negligible,
 // rough_carpet_two_term) or ThreeMixture1 (the caller declared means that differ in the first coordinate only, ip[0] = 1)
@@ -413,6 +473,16 @@ int32_t ptrwm_has_quad_variant(int32_t target_kind, int32_t proposal_kind, int32
   return qi >= 0 && quad_variants(target_kind, false).run[proposal_kind][qi] != nullptr ? 1 : 0;
 }
 
+int32_t ptrwm_auto_form(int32_t target_kind, int32_t proposal_kind, int32_t dim, int32_t n_temps, int64_t n_chains) {
+  if (n_temps < 1 || n_temps > PTRWM_MAX_TEMPS || n_chains < 1) return PTRWM_E_ARG;
+  const bool th = ptrwm_has_thread_variant(target_kind, proposal_kind, dim) != 0;
+  const bool qu = ptrwm_has_quad_variant(target_kind, proposal_kind, dim, n_temps) != 0;
+  if (!th && !qu) return PTRWM_E_NOVARIANT;
+  if (!th) return PTRWM_FORM_QUAD;
+  if (!qu) return PTRWM_FORM_THREAD;
+  return auto_prefers_lane_split(dim, n_temps, n_chains) ? PTRWM_FORM_QUAD : PTRWM_FORM_THREAD;
+}
+
 int32_t ptrwm_has_thread_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim) {
   if (target_kind < 0 || target_kind >= PTRWM_TARGET_COUNT) return 0;
   if (proposal_kind < 0 || proposal_kind >= PTRWM_PROPOSAL_COUNT) return 0;
@@ -481,19 +551,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
       fn = qfn;  // the only form with double state registers (null: ladder too long for a 512-thread workgroup)
       quad = true;
     } else if (qfn != nullptr && (fn == nullptr || form != PTRWM_FORM_THREAD)) {
-      const long long cpw1 = args->n_temps > 64 ? 1 : 64 / args->n_temps;
-      const long long waves1 = args->n_temps > 64 ? args->n_chains * ((args->n_temps + 63) / 64)
-                                                  : (args->n_chains + cpw1 - 1) / cpw1;
-      const double w = (double)waves1 / (double)device_simds();
-      bool faster;
-      if (target->dim < 16)
-        faster = false;  // a lane would own <= 3 dims and most of the quad one Philox block: the thread kernels (dim
-                         // compiled in for 2, 3, 4, 5, 10) are 1.3-1.8x faster even for a single ladder
-      else if (target->dim <= 32)
-        faster = args->n_temps <= 16 ? w < 1.6 : w < 1.0;
-      else
-        faster = w < (target->dim >= 57 ? 2.0 : 0.75);
-      quad = fn == nullptr || form == PTRWM_FORM_QUAD || faster;
+      quad = fn == nullptr || form == PTRWM_FORM_QUAD || auto_prefers_lane_split(target->dim, args->n_temps, args->n_chains);
       if (quad) fn = qfn;
     }
   }

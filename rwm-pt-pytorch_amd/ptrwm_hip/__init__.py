@@ -124,6 +124,7 @@ SYMBOLS = {
     "ptrwm_set_kernel_form": (C.c_int32, [C.c_int32]),
     "ptrwm_has_quad_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "ptrwm_has_thread_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    "ptrwm_auto_form": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
     "ptrwm_run": (C.c_int32, [C.POINTER(TargetDesc), C.POINTER(ProposalDesc), C.POINTER(RunArgs), C.c_void_p]),
     "ptrwm_swap_sweep": (C.c_int32, [C.POINTER(RunArgs), C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "ptrwm_split_propose": (
@@ -284,6 +285,14 @@ def has_quad_variant(target_kind: int, proposal_kind: int, dim: int, n_temps: in
 def has_thread_variant(target_kind: int, proposal_kind: int, dim: int) -> bool:
     """Is there a one-thread-per-replica step kernel for this shape (never above dim 64)?"""
     return bool(load_library().ptrwm_has_thread_variant(target_kind, proposal_kind, dim))
+
+
+def auto_form(target_kind: int, proposal_kind: int, dim: int, n_temps: int, n_chains: int) -> int:
+    """The form FORM_AUTO runs for a launch of this shape on the current device (FORM_THREAD or FORM_QUAD)."""
+    rc = load_library().ptrwm_auto_form(target_kind, proposal_kind, dim, n_temps, n_chains)
+    if rc < 0:
+        raise PTRWMError(rc, "ptrwm_auto_form")
+    return rc
 
 
 def set_kernel_form(form: int) -> int:

@@ -239,3 +239,38 @@ def test_the_binding_stub_printed_in_integration_md_has_the_c_layout(engine):
     call = re.search(r"```python\n(t = TargetDesc\(kind=0.*?)```", text, flags=re.S).group(1)
     used = set(re.findall(r"[(,\s](\w+)=", re.search(r"a = RunArgs\((.*?)\)\nrc", call, flags=re.S).group(1)))
     assert used <= {f[0] for f in engine.RunArgs._fields_}, used - {f[0] for f in engine.RunArgs._fields_}
+
+
+def test_auto_form_rule_is_the_fitted_model(engine):
+    """The form FORM_AUTO picks (ptrwm_auto_form; csrc/form_table.inc) is the model tools/form_fit.py fits to the committed
+    sweep of both forms (profiles/r03_form_sweep_dense.txt): the C++ evaluation and the Python one agree on a grid of
+    dims, ladder lengths and batch sizes off the sweep's own points; on the sweep itself the rule always picks the
+    faster form; and the saw-tooth is there (the thread form at 1.25 waves per SIMD is slower than at 1.0)."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("form_fit", os.path.join(root, "tools", "form_fit.py"))
+    F = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(F)
+    tab = F.load(os.path.join(root, "profiles", "r03_form_sweep_dense.txt"))
+    model = F.fit(tab)
+    assert F.regret(model, tab, "fit data") > 0.999
+    simds = 1024  # no GPU here: the library assumes an MI355X (256 CUs)
+    n = 0
+    for dim in (16, 19, 20, 24, 30, 32, 33, 40, 41, 44, 50, 52, 57, 60, 64):
+        for T in (1, 2, 5, 8, 16, 20, 32, 48, 64):
+            cpw = 64 // T
+            for w in (0.1, 0.3, 0.6, 0.9, 1.0, 1.1, 1.4, 1.6, 1.9, 2.0, 2.2, 2.75, 3.5, 4.0, 5.0):
+                waves = max(1, int(round(w * simds)))
+                C = waves * cpw  # whole waves: w is then exactly waves / simds
+                want = F.quad_faster(model, dim, T, waves / simds)
+                got = engine.auto_form(engine.TARGET_ROUGH_CARPET, engine.PROPOSAL_NORMAL, dim, T, C)
+                assert got == (engine.FORM_QUAD if want else engine.FORM_THREAD), (dim, T, w, C)
+                n += 1
+    assert n > 2000
+    assert engine.auto_form(0, 0, 10, 8, 1) == engine.FORM_THREAD      # dim < 16: never lane-split
+    assert engine.auto_form(0, 0, 100, 8, 10**6) == engine.FORM_QUAD   # dim > 64: the only form
+    assert engine.auto_form(0, 0, 30, 32, 65536) == engine.FORM_THREAD  # BASELINE configs[2]: 8 waves per SIMD
+    a, q = F.params(model, 30, 1)
+    assert a[1] * 1.25 / 2 < a[0]  # the dip of profiles/r02_form_sweep.txt at 81 920 chains
