@@ -317,13 +317,19 @@ def main():
         ms1 = sorted(a.elapsed_time(b) for a, b in ev1)
         ms1_mean = sum(ms1) / n1
         reps_ct = C * T
-        bytes1 = 2 * (reps_ct * dim * 4 + reps_ct * 4 + 3 * reps_ct * 8 + reps_ct * 8)  # read + write: state, logp, 3 x i64, f64
+        # bytes a launch really touches: state and log p read and written, the acceptance counts and the squared-jump sums
+        # read-modify-written (some replica of nearly every cache line accepts), the swap counts and last-swap ordinals only
+        # in the one launch in swap_every that has a swap event (the kernel leaves zero deltas alone)
+        bytes1 = 2 * (reps_ct * dim * 4 + reps_ct * 4 + 2 * reps_ct * 8) + 2 * (2 * reps_ct * 8) / args.swap_every
         inner1 = {"bound": "hbm", "bytes_per_launch": bytes1, "kernel_ms_mean": ms1_mean, "kernel_ms_median": ms1[n1 // 2],
                   "launches": n1, "achieved": bytes1 / (ms1_mean * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                   "frac": bytes1 / (ms1_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                   "chain_mh_steps_per_s": reps_ct / (ms1_mean * 1e-3),
-                  "note": "one MH step per launch: state [C,T,D] f32, log p, accept count, swap count, last-swap ordinal "
-                          "(i64) and squared-jump sum (f64) read once and written once per launch"}
+                  "note": "one MH step per launch.  bytes_per_launch = what the kernel touches: state [C,T,D] f32 and log p read "
+                          "and written, accept counts (i64) and squared-jump sums (f64) read-modify-written, swap counts and "
+                          "last-swap ordinals only in the 1 launch in swap_every with a swap event; `traffic` = the same from "
+                          "the FETCH_SIZE / WRITE_SIZE counters of this command, and frac uses the counters when they are of "
+                          "this build"}
 
     # HBM copy probe (the measured copy bandwidth as a second denominator): 1 GiB device-to-device
     copy_gbps = None
@@ -370,6 +376,10 @@ def main():
                 inner1["traffic"] = rec1.get("hbm_bytes_per_launch")
                 inner1["traffic_source"] = rec1.get("source")
                 inner1["profiled_kernel_ms"] = rec1.get("profiled_kernel_ms")
+                inner1["traffic_of_this_build"] = rec1.get("lib_sha256") == lib_sha
+                if inner1["traffic_of_this_build"] and inner1["traffic"]:
+                    inner1["achieved"] = inner1["traffic"] / (inner1["kernel_ms_mean"] * 1e-3) / 1e9
+                    inner1["frac"] = inner1["achieved"] / HBM_PEAK_GBPS
         clock_ghz = rec.get("shader_clock_ghz", 2.4)
         valu_peak = 1024 * clock_ghz * 1e9 / 2  # 1024 SIMDs, one wave64 VALU instruction per 2 cycles each
         if "valu_insts_per_launch" in rec:
@@ -387,6 +397,17 @@ def main():
         else:  # no PMC record for this configuration: the fraction cannot be stated
             roof = {"bound": "valu_issue", "achieved": None, "peak": valu_peak / 1e9, "unit": "Gwave-instr/s", "frac": None,
                     "traffic": traffic, "note_counters": f"no PMC record {key!r} in profiles/traffic.json"}
+        # cost-weighted issue fraction (tools/issue_model.py: opcode histogram of one Metropolis step x measured per-opcode
+        # issue cost, over the SIMD time a wave-step takes): how busy the VALU pipe is for THIS instruction mix
+        imf = os.path.join(ROOT, "profiles", "r03_issue_model.json")
+        if wl == "cfg3" and os.path.exists(imf):
+            with open(imf) as f:
+                im = json.load(f)
+            roof["issue_cost_weighted"] = {
+                "frac": im.get("issue_cost_weighted"), "busy_ns_per_wave_step": im.get("busy_ns_per_wave_step"),
+                "ns_per_wave_step": im.get("ns_per_wave_step"), "valu_on_step_path": im.get("valu_on_path"),
+                "pmc_check": im.get("pmc_check"), "source": "profiles/r03_issue_model.txt (tools/issue_model.py, tools/issue_cost.hip)",
+                "model_of_this_build": im.get("lib_sha256") == lib_sha}
         roof.update({
             "kernel": rec.get("kernel") or f"fused step kernel <{type(target).__name__}, {alg.proposal_dist.get_name()}, dim {dim}, "
                                            "production>, form chosen by the C ABI",

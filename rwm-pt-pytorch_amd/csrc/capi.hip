@@ -25,8 +25,8 @@ struct VariantPair {
 // per SIMD the one-thread-per-replica form would launch:
 //   thread form   rate = A(k) w / k, k = ceil(w): a launch lasts as long as its fullest SIMDs, so at w = 1.25 the form
 //                 runs at 0.625 of its two-waves rate, not at its one-wave rate (the dips of profiles/r02_form_sweep.txt)
-//   lane-split    four times the waves with a quarter of the work each: its saw-tooth is four times finer and lives in
-//                 the measured curve Q(w)
+//   lane-split    four times the waves with a quarter of the work each: the same saw-tooth on a four times finer scale,
+//                 rate = Q(kq / 4) 4 w / kq, kq = ceil(4 w), Q read off the measured curve
 //   dim < 16      never lane-split (a lane would own <= 3 dims: profiles/r02_single_ladder.txt)
 //   dim > 64      always: it is the only form there (the one-thread-per-replica kernel needed 340-420 VGPRs and sat in
 //                 the register regime in which hipcc miscompiled it twice; see variants.h)
@@ -73,15 +73,25 @@ static bool lane_split_is_faster(int dim, int n_temps, double w) {
   int k = (int)__builtin_ceil(w - 1e-9);
   if (k < 1) k = 1;
   const double thread = a[k - 1] * w / k;
-  double quad;
-  if (w <= kFormW[0]) {
-    quad = q[0] * w / kFormW[0];
-  } else {
-    int i = 0;
-    while (i + 2 < kFormNW && kFormW[i + 1] <= w) ++i;
-    quad = q[i] + (q[i + 1] - q[i]) * (w - kFormW[i]) / (kFormW[i + 1] - kFormW[i]);
+  // the lane-split form: the same saw-tooth on its four times finer scale - the measured rate at the next whole number of
+  // lane-split waves per SIMD, times the fill of that last wave slot
+  // (ladders of more than 16 temperatures: a whole workgroup of 2-8 waves per ladder is the unit and the dispatcher spreads
+  // them over the CUs: no saw-tooth of its own, the measured curve is interpolated as it is)
+  double kq = 4.0 * w;
+  if (n_temps <= 16) {
+    kq = __builtin_ceil(4.0 * w - 1e-9);
+    if (kq < 1.0) kq = 1.0;
   }
-  return quad > thread;
+  double wu = kq / 4.0, b;
+  if (wu <= kFormW[0]) {
+    b = q[0];
+  } else {
+    if (wu > kFormW[kFormNW - 1]) wu = kFormW[kFormNW - 1];
+    int i = 0;
+    while (i + 2 < kFormNW && kFormW[i + 1] <= wu + 1e-9) ++i;
+    b = q[i] + (q[i + 1] - q[i]) * (wu - kFormW[i]) / (kFormW[i + 1] - kFormW[i]);
+  }
+  return b * (4.0 * w / kq) > thread;
 }
 
 static int g_kernel_form = PTRWM_FORM_AUTO;  // read / written with __atomic builtins (ptrwm_set_kernel_form may race with a launch)
@@ -288,7 +298,7 @@ __global__ void __launch_bounds__(256) swap_sweep_kernel(const SweepArgs a) {
   bool pair_acc = false;
   __shared__ int s_landed[256];
   swap_decide(T, t, 0, t, a.swap_mode, a.swap_order, (int)(a.event_index & 1), a.beta, a.beta[t], us, s_l, s_u, s_landed,
-              my_l, src, pair_acc);
+              my_l, src, pair_acc, [] { __syncthreads(); }, [](bool p) -> bool { return __syncthreads_and(p ? 1 : 0) != 0; });
   if (live) s_src[tid] = src;
   __syncthreads();
   float *gs = a.state + chain * T * (long long)D;

@@ -96,33 +96,66 @@ __device__ __forceinline__ bool mh_accept(float beta_t, float lp_new, float lp, 
 // stand-alone sweep kernel (capi.hip).  In: this thread's temperature t (0 for idle threads), base = slot of
 // temperature 0 of its ladder, slot = base + t, us = its swap uniform, my_l = its log-density; s_l / s_u = the
 // ladder's published log-densities and uniforms (already synchronised), landed = one int of LDS scratch per slot;
-// par = parity of the event (even/odd order).
+// par = parity of the event (even/odd order); sync = the group's barrier, all_of = a vote over the group (both called by
+// every thread of the group, or by none).
 // Out: my_l = the log-density that ends up at temperature t, src = the slot whose vector does, pair_acc = pair
 // (t, t+1) accepted (recorded on the thread of temperature t).
+//
+// Sequential exchange sweep, threshold form.  The sweep j = 0..T-2 carries one state upward: at pair j the state now at
+// position j (log-density c) meets the untouched state of position j+1 (log-density l_k), and the reference accepts when
+//   u_j < min(1, exp((b_j - b_k)(l_k - c)))          (fused_swap_probability_calculation, :37-48, :617-621).
+// For b_j > b_k (a ladder ordered cold to hot) that is   c < l_k - ln(u_j) / (b_j - b_k) =: thr_j,   and thr_j does not
+// depend on the carried state: every thread computes the threshold of its own pair ONCE (one v_log_f32, one v_rcp_f32),
+// publishes it in place of its uniform, and the scan that every thread of the ladder replays shrinks from four products,
+// three sums, an exponential and two compares per pair to ONE compare per pair (plus the selects that carry the state):
+// ~22 -> ~6 VALU instructions per pair, 4 % of BASELINE configs[2]'s instructions.  Same decisions up to rounding of the
+// threshold (both forms are within a few ulp of the exact boundary; tests prove every decision that differs from the
+// oracle's literal evaluation).  The reference's corner cases keep its literal rule: if any pair of the group has
+// b_j <= b_k, or any log-density is -inf or NaN (its four-product sum is then NaN and the swap is refused), the whole
+// group takes the literal scan below.
+template <class Sync, class AllOf>
 __device__ __forceinline__ void swap_decide(int T, int t, int base, int slot, int swap_mode, int swap_order, int par,
                                             const float *__restrict__ beta, float beta_t, float us, const float *s_l,
-                                            const float *s_u, int *landed, float &my_l, int &src, bool &pair_acc) {
+                                            float *s_u, int *landed, float &my_l, int &src, bool &pair_acc, Sync sync,
+                                            AllOf all_of) {
   if (swap_order == PTRWM_ORDER_SEQUENTIAL) {
     if (swap_mode == PTRWM_SWAP_EXCHANGE) {
-      // The sweep j = 0..T-2 carries one state upward: at pair j the state now at position j (carried) meets
-      // the still-untouched state of position j+1.  Every thread of the ladder replays the scan from the
-      // published original values (uniform addresses: LDS broadcasts, no dependent cross-lane traffic) and
-      // keeps what lands on its own position.
+      const bool has_k = t < T - 1;
+      const float db = has_k ? sub_rn(beta_t, beta[t + 1]) : 1.0f;
+      const bool plain = all_of(db > 0.0f && my_l > kNegInf);  // (NaN compares false)
       float car_l = s_l[base];
       int car_i = base;
+      if (plain) {
+        // own pair's threshold in place of its uniform (u = 0: ln = -inf, threshold +inf: accepted, as u < exp(..) is)
+        const float lk = s_l[has_k ? slot + 1 : slot];
+        s_u[slot] = fmaf(-hw_ln(us), __builtin_amdgcn_rcpf(db), lk);
+        sync();
 #pragma unroll 2
-      for (int j = 0; j < T - 1; ++j) {
-        const float lk = s_l[base + j + 1];
-        const float u = s_u[base + j];
-        const float bj = beta[j], bk = beta[j + 1];
-        const bool ok = swap_accept_test(u, swap_log_prob(bj, bk, car_l, lk));
-        const int ik = base + j + 1;
-        // Every thread of the ladder computes the same values, so the outcome for position j (which slot's vector
-        // lands there) is written to LDS by all of them, identically, and each thread picks up its own position
-        // after the loop: one ds_write per pair instead of a compare and three selects on t == j.
-        landed[base + j] = ok ? ik : car_i;
-        car_l = ok ? car_l : lk;
-        car_i = ok ? car_i : ik;
+        for (int j = 0; j < T - 1; ++j) {
+          const int ik = base + j + 1;
+          const float lkj = s_l[ik];
+          const bool ok = car_l < s_u[base + j];
+          landed[base + j] = ok ? ik : car_i;
+          car_l = ok ? car_l : lkj;
+          car_i = ok ? car_i : ik;
+        }
+      } else {
+        // the literal scan: every thread of the ladder replays the sweep from the published original values (uniform
+        // addresses: LDS broadcasts, no dependent cross-lane traffic) and keeps what lands on its own position
+#pragma unroll 2
+        for (int j = 0; j < T - 1; ++j) {
+          const float lk = s_l[base + j + 1];
+          const float u = s_u[base + j];
+          const float bj = beta[j], bk = beta[j + 1];
+          const bool ok = swap_accept_test(u, swap_log_prob(bj, bk, car_l, lk));
+          const int ik = base + j + 1;
+          // Every thread of the ladder computes the same values, so the outcome for position j (which slot's vector
+          // lands there) is written to LDS by all of them, identically, and each thread picks up its own position
+          // after the loop: one ds_write per pair instead of a compare and three selects on t == j.
+          landed[base + j] = ok ? ik : car_i;
+          car_l = ok ? car_l : lk;
+          car_i = ok ? car_i : ik;
+        }
       }
       landed[base + T - 1] = car_i;
       // (a wave's LDS operations complete in program order, and every wave of a wide ladder writes all positions
@@ -222,13 +255,13 @@ __device__ __forceinline__ void stage_copy(float *__restrict__ lds, float *__res
 // the value, re-materialised in a VGPR at this point: stops the compiler from sharing (and keeping live) anything
 // derived from it with code before this point
 __device__ __forceinline__ int opaque_vgpr(int v) {
-  asm volatile("" : "+v"(v));
+  PTRWM_VALUE_BARRIER("+v"(v));
   return v;
 }
 
 template <bool EXACT>
 __device__ __forceinline__ int fresh_dim(int d0) {
-  if constexpr (!EXACT) asm volatile("" : "+s"(d0));
+  if constexpr (!EXACT) PTRWM_VALUE_BARRIER("+s"(d0));
   return d0;
 }
 
@@ -239,7 +272,7 @@ __device__ __forceinline__ int fresh_dim(int d0) {
 typedef const __attribute__((address_space(4))) KArgs *kargs_ptr;
 __device__ __forceinline__ kargs_ptr late_args() {
   uintptr_t p = (uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(p));
+  PTRWM_VALUE_BARRIER("+s"(p));
   return (kargs_ptr)p;
 }
 
@@ -257,9 +290,12 @@ __device__ __forceinline__ kargs_ptr late_args() {
 #ifndef PTRWM_WAVES_MID
 #define PTRWM_WAVES_MID 2
 #endif
-// (Width 40 at 4 waves/SIMD spilled ~75 VGPRs; 3 waves/SIMD = 168 VGPRs holds it.)
+// (Width 40 at 4 waves/SIMD spilled ~75 VGPRs; 3 waves/SIMD = 168 VGPRs holds it.  The generic width 32 sat at 125 of the
+// 128 VGPRs that 4 waves/SIMD allow and spilled two of them to scratch once the swap event grew its threshold form: it
+// is compiled for 3 waves/SIMD as well - dims 31 and 32 run at ~0.97 of the 4-wave rate (profiles/r03_form_sweep_dense.txt,
+// A(3)), everything up to the exact width 30 keeps 4.)
 constexpr int min_waves_per_simd(int dp) {
-  return dp <= 36 ? PTRWM_WAVES_SMALL : (dp <= 44 ? PTRWM_WAVES_40 : (dp <= 64 ? PTRWM_WAVES_MID : 1));
+  return dp <= 30 ? PTRWM_WAVES_SMALL : (dp <= 44 ? PTRWM_WAVES_40 : (dp <= 64 ? PTRWM_WAVES_MID : 1));
 }
 
 // DP    compile-time width of the per-thread register arrays (>= dim)
@@ -303,6 +339,8 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       __builtin_amdgcn_wave_barrier();
     }
   };
+  // does the predicate hold on every thread of the exchange group?  (called by all of them)
+  auto group_all = [&](bool p) -> bool { return wide ? (__syncthreads_and(p ? 1 : 0) != 0) : (__builtin_amdgcn_ballot_w64(!p) == 0ull); };
 
   // ---- state load: coalesced HBM reads staged through LDS ------------------------------------------------
   // The group's live replicas are one contiguous run of n_live * dim floats in `state`.  The group copies that
@@ -445,7 +483,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       s_u[slot] = us;
       sync_group();
       swap_decide(T, t, base, slot, a.swap_mode, a.swap_order, (ev_par0 + swap_in_call) & 1, a.beta, beta_t, us, s_l, s_u,
-                  reinterpret_cast<int *>(s_u + group_threads), my_l, src, pair_acc);
+                  reinterpret_cast<int *>(s_u + group_threads), my_l, src, pair_acc, sync_group, group_all);
       if (pair_acc) {
         park[group_threads] += 1;
         park[2 * group_threads] = swap_in_call;

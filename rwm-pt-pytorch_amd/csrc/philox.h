@@ -73,6 +73,19 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
   return u32x4{c0, c1, c2, c3};
 }
 
+// Value barriers.  PTRWM_VALUE_BARRIER("+s" / "+v", x) is an EMPTY inline asm that names x as read and written: no
+// instruction, but the optimiser must treat x as a new value from here on - it can neither hoist what is computed from it
+// out of the step loop nor share it with the code before.  Every use in this library is of that kind (kernel.h opaque_vgpr
+// / fresh_dim / late_args, uniform_vec below, quad.h q_fresh, targets.h HybridRosenbrock) and exists to keep loop-invariant
+// values out of registers - i.e. out of spill lanes - across the ~1 500-instruction step loop.  Building with
+// -DPTRWM_NO_VALUE_BARRIERS removes all of them (analysis only: tools/barrier_diff.py compiles both ways and records what
+// they do to registers, spills and scratch, profiles/r03_barrier_diff.txt).
+#ifdef PTRWM_NO_VALUE_BARRIERS
+#define PTRWM_VALUE_BARRIER(...) ((void)0)
+#else
+#define PTRWM_VALUE_BARRIER(...) asm volatile("" : __VA_ARGS__)
+#endif
+
 // Parameter vectors (means, per-dimension scales) are read-only for the whole launch and indexed wave-uniformly.
 // Read through the constant address space they become scalar loads (s_load_dwordx*, SGPR operands) instead of
 // 64-lane vector loads of a single address.  (No kernel writes them, so the scalar cache cannot go stale.)
@@ -81,7 +94,7 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 typedef const __attribute__((address_space(4))) float *const_float_ptr;
 __device__ __forceinline__ const_float_ptr uniform_vec(const float *p) {
   uintptr_t v = (uintptr_t)p;
-  asm volatile("" : "+s"(v));
+  PTRWM_VALUE_BARRIER("+s"(v));
   return (const_float_ptr)v;
 }
 
@@ -89,7 +102,7 @@ __device__ __forceinline__ const_float_ptr uniform_vec(const float *p) {
 // this point - used every few dimensions to bound how many parameter words are in flight (in SGPRs) at once
 __device__ __forceinline__ const_float_ptr uniform_vec_again(const_float_ptr p) {
   uintptr_t v = (uintptr_t)p;
-  asm volatile("" : "+s"(v));
+  PTRWM_VALUE_BARRIER("+s"(v));
   return (const_float_ptr)v;
 }
 

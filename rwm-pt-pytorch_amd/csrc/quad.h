@@ -77,7 +77,7 @@ struct QLane {
 // dozens of SGPR pairs, spilled to VGPR lanes and fetched back with v_readlane (157 SGPR spills at width 28; dims
 // 65..104 other than 100 gained 3-9 %, dims 16..64 in this form 2-3 %).
 __device__ __forceinline__ int q_fresh(int v) {
-  asm volatile("" : "+v"(v));
+  PTRWM_VALUE_BARRIER("+v"(v));
   return v;
 }
 // valid(j): does local slot j hold a dimension?  MIN_OWN (a compile-time lower bound of n_own over the four lanes, known
@@ -337,7 +337,7 @@ struct QThreeMixture1 {
     float cl = 0.0f;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-      if (l.d0 + j >= 1 && q_valid<MIN_OWN>(l, j)) {
+      if ((j >= 1 || l.q != 0) && q_valid<MIN_OWN>(l, j)) {  // every dimension but the first (dimension 0 = slot 0 of lane 0)
         float e;
         if constexpr (SCALED) {
           e = fmaf(y[j], sc_v[j], -mu[j]);
@@ -374,9 +374,10 @@ struct QFullRosenbrock {
     const float *mu = tp.vec0 + l.d0;
     const float halo = dpp_f<kDppNext>(y[0]);  // x_{i+1} of this lane's last term lives in the next lane
     float s1 = 0.0f, s2 = 0.0f;
+    const int d0f = q_fresh(l.d0);  // (q_fresh: the per-slot lane masks are rebuilt here, not hoisted out of the step loop)
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-      if (l.d0 + j + 1 < D) {  // term i = d0 + j exists (then slot j is owned)
+      if (d0f + j + 1 < D) {  // term i = d0 + j exists (then slot j is owned)
         const float nxt = (j + 1 < W) ? y[j + 1 < W ? j + 1 : 0] : halo;
         const float r = nxt - y[j] * y[j];
         const float c = y[j] - mu[j];
@@ -397,9 +398,10 @@ struct QEvenRosenbrock {
     const float a = tp.p[0], b = tp.p[1];
     const float *mu = tp.vec0 + (l.d0 >> 1);  // one mu per pair; W is a multiple of 4, so pairs never straddle lanes
     float s1 = 0.0f, s2 = 0.0f;
+    const int d0f = q_fresh(l.d0);
 #pragma unroll
     for (int i = 0; 2 * i + 1 < W; ++i) {
-      if (l.d0 + 2 * i + 1 < D) {
+      if (d0f + 2 * i + 1 < D) {
         const float c = y[2 * i] - mu[i];
         const float r = y[2 * i + 1] - y[2 * i] * y[2 * i];
         s1 = fmaf(a * c, c, s1);
@@ -421,9 +423,10 @@ struct QHybridRosenbrock {
     const float halo = dpp_f<kDppPrev>(y[W - 1]);  // x_{i-1} of this lane's first coordinate lives in the previous lane
     const float c0 = y0 - mu;
     float acc = (l.q == 0) ? a * c0 * c0 : 0.0f;  // the x_0 term opens the chain of the first range
+    const int d0f = q_fresh(l.d0);
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-      const int i = l.d0 + j;
+      const int i = d0f + j;
       if (i >= 1 && i < D) {
         const bool head = (tp.mask[i >> 6] >> (i & 63)) & 1ull;
         const float prev = (j > 0) ? y[j > 0 ? j - 1 : 0] : halo;
@@ -539,9 +542,10 @@ struct QNealFunnel {
     const float dv = v - mu_v;
     const float prior = -0.5f * log_2pi - 0.5f * (hw_log2(s2) * kLn2) - 0.5f * (dv * dv) / s2;
     float ssl = 0.0f;
+    const int d0f = q_fresh(l.d0);
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-      if (l.d0 + j >= 1 && q_valid<MIN_OWN>(l, j)) {
+      if (d0f + j >= 1 && q_valid<MIN_OWN>(l, j)) {
         const float c = y[j] - mu_z;
         ssl = fmaf(c, c, ssl);
       }
@@ -798,19 +802,39 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
         // published values that every thread replays) would be replayed by every one of them - four times the work per
         // ladder of the one-thread-per-replica kernel.  Here ONE lane per ladder runs the scan and publishes, for every
         // position, the slot whose vector lands there; a barrier later everyone picks up its own position.  Same
-        // decisions, same values (the scan code is swap_decide's).
+        // decisions, same values: the threshold form of swap_decide (every quad turns its pair's uniform into a threshold
+        // on the carried log-density first) or, for ladders it does not cover, the literal scan.
+        const bool has_k = t < T - 1;
+        const float db = has_k ? sub_rn(beta_t, a.beta[t + 1]) : 1.0f;
+        const bool plain = __syncthreads_and((db > 0.0f && my_l > kNegInf) ? 1 : 0) != 0;
+        if (plain) {
+          const float lk = s_l[has_k ? slot_raw + 1 : slot_raw];
+          s_u[slot_raw] = fmaf(-hw_ln(us), __builtin_amdgcn_rcpf(db), lk);  // (the four lanes of a quad write the same value)
+          __syncthreads();
+        }
         if ((int)threadIdx.x < cpw) {  // lane i of the first wavefront scans ladder i of the workgroup
           const int b0 = (int)threadIdx.x * T;
           float car_l = s_l[b0];
           int car_i = b0;
+          if (plain) {
+#pragma unroll 4
+            for (int j = 0; j < T - 1; ++j) {
+              const float lk = s_l[b0 + j + 1];
+              const bool ok = car_l < s_u[b0 + j];
+              s_landed[b0 + j] = ok ? b0 + j + 1 : car_i;
+              car_l = ok ? car_l : lk;
+              car_i = ok ? car_i : b0 + j + 1;
+            }
+          } else {
 #pragma unroll 2
-          for (int j = 0; j < T - 1; ++j) {
-            const float lk = s_l[b0 + j + 1];
-            const float u = s_u[b0 + j];
-            const bool ok = swap_accept_test(u, swap_log_prob(a.beta[j], a.beta[j + 1], car_l, lk));
-            s_landed[b0 + j] = ok ? b0 + j + 1 : car_i;
-            car_l = ok ? car_l : lk;
-            car_i = ok ? car_i : b0 + j + 1;
+            for (int j = 0; j < T - 1; ++j) {
+              const float lk = s_l[b0 + j + 1];
+              const float u = s_u[b0 + j];
+              const bool ok = swap_accept_test(u, swap_log_prob(a.beta[j], a.beta[j + 1], car_l, lk));
+              s_landed[b0 + j] = ok ? b0 + j + 1 : car_i;
+              car_l = ok ? car_l : lk;
+              car_i = ok ? car_i : b0 + j + 1;
+            }
           }
           s_landed[b0 + T - 1] = car_i;
         }
@@ -820,7 +844,8 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
         pair_acc = (t < T - 1) && (src == base + t + 1);
       } else {
         swap_decide(T, t, base, slot, a.swap_mode, a.swap_order, (ev_par0 + swap_in_call) & 1, a.beta, beta_t, us, s_l, s_u,
-                    s_landed, my_l, src, pair_acc);
+                    s_landed, my_l, src, pair_acc, sync_group,
+                    [&](bool p) -> bool { return wide ? (__syncthreads_and(p ? 1 : 0) != 0) : (__builtin_amdgcn_ballot_w64(!p) == 0ull); });
       }
       if (pair_acc) {
         n_swap_acc += 1;

@@ -275,7 +275,7 @@ struct HybridRosenbrock {
     // step loop - up to 128 SGPRs that live for the whole launch, i.e. in spill lanes (110-163 spilled SGPRs in these
     // kernels before; tools/kernel_stats.py)
     unsigned long long mask[2] = {tp.mask[0], tp.mask[1]};
-    asm volatile("" : "+s"(mask[0]), "+s"(mask[1]));
+    PTRWM_VALUE_BARRIER("+s"(mask[0]), "+s"(mask[1]));
     PTRWM_DIM_LOOP(i, DP, D, {
       if (i >= 1) {
         const bool head = (mask[i >> 6] >> (i & 63)) & 1ull;
@@ -283,7 +283,7 @@ struct HybridRosenbrock {
         // y[] dynamically indexed and moves the whole vector to scratch memory (16 + 4 DP bytes per thread, found by
         // tools/kernel_stats.py --check); the empty asm pins the second candidate in a register first
         float prev = y[i - 1];
-        asm volatile("" : "+v"(prev));
+        PTRWM_VALUE_BARRIER("+v"(prev));
         const float parent = head ? y[0] : prev;
         const float r = y[i] - parent * parent;
         acc[i / W] = fmaf(b * r, r, acc[i / W]);

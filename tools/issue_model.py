@@ -146,7 +146,18 @@ def main():
     ap.add_argument("--flags", default=None, help="compile flags of the TU's group (default: the Makefile's max-ILP group)")
     ap.add_argument("--asm", default=None, help="an annotated .s to reuse instead of compiling")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--from-traffic", default=None, help="key of profiles/traffic.json to take the PMC counts and the kernel time "
+                                                         "of (a launch without swap events), e.g. pt_d30_T32_C65536_noswap")
     a = ap.parse_args()
+    lib_sha = None
+    if a.from_traffic:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[a.from_traffic]
+        waves, steps = rec["waves_per_launch"], rec["mh_steps_per_launch"]
+        a.valu_per_wave_step = rec["valu_insts_per_launch"] / (waves * steps)
+        a.salu_per_wave_step = rec["salu_insts_per_launch"] / (waves * steps)
+        a.ns_per_wave_step = rec["profiled_kernel_ms"] * 1e6 * 1024 / (waves * steps)  # 1024 SIMDs
+        lib_sha = rec["lib_sha256"]
+        print(f"PMC record {a.from_traffic}: {waves:.0f} waves x {steps} steps per launch, {rec['profiled_kernel_ms']:.3f} ms")
     asm = a.asm or compile_tu(a.tu, a.flags.split() if a.flags is not None else SCHED)
     name, blocks, order = kernel_blocks(asm, a.kernel)
     header, path, pen = step_path(blocks, order)
@@ -195,7 +206,7 @@ def main():
                    "pmc_check": {"valu_per_wave_step": a.valu_per_wave_step, "salu_per_wave_step": a.salu_per_wave_step, "ok": ok},
                    "ns_per_wave_step": a.ns_per_wave_step,
                    "issue_cost_weighted": (busy / a.ns_per_wave_step) if (costs and a.ns_per_wave_step) else None,
-                   "costs": os.path.relpath(a.costs, ROOT), "waves": a.waves}, open(a.json, "w"), indent=1)
+                   "costs": os.path.relpath(a.costs, ROOT), "waves": a.waves, "lib_sha256": lib_sha}, open(a.json, "w"), indent=1)
     sys.exit(0 if ok else 1)
 
 

@@ -6,9 +6,11 @@
 # gpurun_out/prof_<tag>/; tools/profile_summary.py then writes the summaries under profiles/.  Counters are collected
 # in their own runs (one TCC counter per pass), never together with API tracing; the program after `--` is python3 itself.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=/root/repo/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+# per-opcode issue costs on this box (tools/issue_cost.hip), the price list of tools/issue_model.py
+if [ -x /root/repo/tools/issue_cost ]; then /root/repo/tools/issue_cost > /root/repo/profiles/${TAG}_issue_costs.json 2> "$OUT/issue_cost.err" || true; fi
 cd /tmp
 export TMPDIR=/tmp
 B="python3 /root/repo/bench.py --cpu-seconds 0 --no-extras"
@@ -23,6 +25,14 @@ prof() {  # prof <name> <kernel-trace steps> <pmc steps> <bench args...>
   echo "profiled $name"
 }
 prof cfg3 20 4
+# the same launch without swap events (swap_every beyond the horizon): the reference count of tools/issue_model.py, whose
+# static opcode histogram of one Metropolis step must reproduce these SQ_INSTS_VALU / SQ_INSTS_SALU per wave-step
+prof cfg3_noswap 10 3 --swap-every 1073741824
+# instruction mix of the headline launch by class, as the hardware counts it (two more SQ passes)
+for grp in "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32" "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_LDS"; do
+  n=$(echo $grp | cut -d' ' -f1)
+  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$OUT/cfg3/pmc_MIX_$n" -o p -- $B --steps 4 --warmup 1 > "$OUT/cfg3.pmc_MIX_$n.log" 2>&1 || echo "(class counters $n not collected)"
+done
 prof cfg3_inner1 200 40 --inner 1
 prof cfg2 20 4 --workload cfg2
 prof cfg4 10 3 --workload cfg4 --inner 500
@@ -31,6 +41,9 @@ cd /root/repo
 timeout -k 10 500 python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 echo "bench done"
 python3 tools/profile_summary.py "$TAG" "$OUT"
+# cost-weighted issue model of the headline kernel (recompiles one translation unit with -save-temps: ~1 min of CPU)
+python3 tools/issue_model.py --from-traffic pt_d30_T32_C65536_noswap --costs profiles/${TAG}_issue_costs.json \
+    --json profiles/${TAG}_issue_model.json > profiles/${TAG}_issue_model.txt 2>&1 || tail -5 profiles/${TAG}_issue_model.txt
 # second bench run so that the committed line carries the counters of THIS build (traffic.json was just rewritten)
 timeout -k 10 500 python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 cp "$OUT/bench_n1.json" profiles/${TAG}_bench_n1.json

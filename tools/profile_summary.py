@@ -25,6 +25,7 @@ lib_sha = hashlib.sha256(open(LIB, "rb").read()).hexdigest()
 # cfg -> (traffic.json key, Metropolis steps per launch, description, warm-up launches in the kernel-trace run)
 CFGS = {
     "cfg3": ("pt_d30_T32_C65536", None, "BASELINE configs[2]: 65536 ladders x 32 temps", 3),
+    "cfg3_noswap": ("pt_d30_T32_C65536_noswap", None, "BASELINE configs[2] with swap_every beyond the horizon (no swap events)", 3),
     "cfg3_inner1": ("pt_d30_T32_C65536_inner1", 1, "BASELINE configs[2], ONE Metropolis step per launch", 3),
     "cfg2": ("rwm_d30_T1_C65536", None, "BASELINE configs[1]: 65536 chains x 1 temperature", 3),
     "cfg4": ("cfg4", 500, "BASELINE configs[3] per-GPU shard: EvenRosenbrock d30, Laplace, 32 temps, 65536 ladders, 500 steps per launch", 3),
@@ -74,6 +75,11 @@ for cfg, (key, inner, desc, warm) in CFGS.items():
     allc = {}
     for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_GRBM_GUI_ACTIVE", "pmc_SQ"):
         allc.update(counters(os.path.join(base, sub)))
+    for sub in sorted(glob.glob(os.path.join(base, "pmc_MIX_*"))):  # instruction-class counters (headline launch only)
+        try:
+            allc.update(counters(sub))
+        except SystemExit:
+            pass
     with open(os.path.join(prof, f"{tag}_pmc_{cfg}.csv"), "w") as f:
         f.write(f"# rocprofv3 --pmc <counter> --output-format csv -- python3 bench.py --cpu-seconds 0 --no-extras ... ({desc}); "
                 "one pass per TCC counter, SQ counters in one pass; per dispatch of the step kernel\n")
@@ -101,6 +107,11 @@ for cfg, (key, inner, desc, warm) in CFGS.items():
         "grbm_gui_active_per_launch_sum_over_8_xcd": mean["GRBM_GUI_ACTIVE"], "profiled_kernel_ms": mean_ms,
         "shader_clock_ghz": clock, "lib_sha256": lib_sha, "kernel": kname,
     }
+    mix = {k: v for k, v in mean.items() if k.startswith("SQ_INSTS_VALU_") or k == "SQ_INSTS_LDS"}
+    if mix:
+        tj[key]["instruction_classes_per_launch"] = mix
+    if "SQ_WAVES" in mean:
+        tj[key]["waves_per_launch"] = mean["SQ_WAVES"]
     print(f"{cfg}: {len(rows)} dispatches, mean of the timed ones {mean_ms:.4f} ms; HBM {(fetch + write) / 1e6:.1f} MB/launch "
           f"({(fetch + write) / (mean_ms * 1e-3) / 1e12:.2f} TB/s); VALU {mean['SQ_INSTS_VALU']:.4g} wave-insts/launch; "
           f"clock {clock:.3f} GHz")
