@@ -39,9 +39,14 @@ static void form_lerp(const float *a, const float *b, float t, float *out, int n
 
 // interpolated model parameters at (dim, n_temps): dims within the lane-width class of `dim`, ladder lengths in log2
 static void form_params(int dim, int n_temps, float *thread4, float *quad) {
-  int d0 = -1, d1 = -1;  // last grid dim <= dim and first grid dim >= dim, within dim's lane-width class
-  for (int i = 0; i < kFormND; ++i) {
-    if ((kFormDims[i] <= 32) != (dim <= 32)) continue;
+  // A dim with kernels of its own (dim compiled in) has its own row; every other dim runs the run-time-dim kernels: last
+  // generic grid dim <= dim and first generic grid dim >= dim within dim's lane-width class
+  int d0 = -1, d1 = -1;
+  for (int i = 0; i < kFormND; ++i)
+    if (kFormDimExact[i] && kFormDims[i] == dim) d0 = d1 = i;
+  const bool own_row = d0 >= 0;
+  for (int i = 0; i < kFormND && !own_row; ++i) {
+    if (kFormDimExact[i] || (kFormDims[i] <= 32) != (dim <= 32)) continue;
     if (kFormDims[i] <= dim) d0 = i;
     if (kFormDims[i] >= dim && d1 < 0) d1 = i;
   }

@@ -12,7 +12,7 @@ namespace ptrwm {
 #define STUB(fn) const TargetVariants &fn##_narrow() { static const TargetVariants v = {}; return v; } \
                  const TargetVariants &fn##_wide() { static const TargetVariants v = {}; return v; } \
                  const QuadVariants &fn##_quad() { static const QuadVariants v = {}; return v; }
-STUB(three_mixture_variants) STUB(full_rosenbrock_variants) STUB(even_rosenbrock_variants)
+STUB(three_mixture_variants) STUB(three_mixture1_variants) STUB(full_rosenbrock_variants) STUB(even_rosenbrock_variants)
 STUB(hybrid_rosenbrock_variants) STUB(iid_gamma_variants) STUB(iid_beta_variants) STUB(diag_gaussian_variants)
 STUB(hypercube_variants) STUB(neal_funnel_variants)
 }

@@ -12,8 +12,10 @@ The model.  w = wavefronts per SIMD the one-thread-per-replica form would launch
   lane-split:   four times the waves, a quarter of the work each: the same saw-tooth on a four times finer scale,
                 rate(w) = Q(kq / 4) * 4 w / kq,  kq = ceil(4 w), with Q read off the measured curve (the sweep's w values are
                 multiples of 0.25 up to 2, i.e. whole numbers of lane-split waves per SIMD; linear in between beyond).
-Both are stored relative to A(4) per (dim, temperatures); between grid dims of the same lane-width class and between grid
-ladder lengths (in log2 T) the table is interpolated linearly.  AUTO picks the lane-split form where Q(w) > rate(w)."""
+Both are stored relative to A(4) per (dim, temperatures).  A dim with kernels of its own (dim compiled in: 20, 30, 50) uses its
+own row; every other dim runs the run-time-dim kernels and is interpolated linearly between the generic grid dims of its
+lane-width class (compiled-in kernels are 10-40 % faster per dimension than their generic neighbours, in both forms, so
+the two families cannot share rows); between grid ladder lengths the table is interpolated in log2 T.  AUTO picks the lane-split form where Q(w) > rate(w)."""
 import collections
 import math
 import sys
@@ -44,9 +46,15 @@ def lerp(a, b, t):
     return [x + (y - x) * t for x, y in zip(a, b)]
 
 
+EXACT_DIMS = (2, 3, 4, 5, 10, 20, 30, 50)  # dims with kernels of their own (dim compiled in: csrc/variants.h), both forms
+
+
 def params(model, dim, T):
     dims, temps, ws, A, Q = model
-    cls = [d for d in dims if (d <= 32) == (dim <= 32)]
+    if dim in EXACT_DIMS and dim in dims:
+        cls = [dim]  # its own kernels: its own row of the table
+    else:  # a run-time-dim kernel: between the generic grid dims of the same lane-width class
+        cls = [d for d in dims if (d <= 32) == (dim <= 32) and d not in EXACT_DIMS]
     d0 = max([d for d in cls if d <= dim], default=cls[0])
     d1 = min([d for d in cls if d >= dim], default=cls[-1])
     td = 0.0 if d0 == d1 else (dim - d0) / (d1 - d0)
@@ -106,6 +114,7 @@ def main():
     f = lambda v: ", ".join(f"{x:.4f}f" for x in v)  # noqa: E731
     print(f"// generated by tools/form_fit.py from {sys.argv[1]} - do not edit; see the tool for the model")
     print(f"constexpr int kFormDims[] = {{{', '.join(map(str, dims))}}};")
+    print(f"constexpr bool kFormDimExact[] = {{{', '.join('true' if d in EXACT_DIMS else 'false' for d in dims)}}};  // a kernel with this dim compiled in")
     print(f"constexpr int kFormTemps[] = {{{', '.join(map(str, temps))}}};")
     print(f"constexpr float kFormW[] = {{{f(ws)}}};")
     print(f"constexpr int kFormND = {len(dims)}, kFormNT = {len(temps)}, kFormNW = {len(ws)};")

@@ -37,7 +37,9 @@ def dense(held_out=False):
     """The table the AUTO rule of csrc/capi.hip is fitted on (and, with held_out, the one it is checked against): both
     pinned forms and AUTO over waves-per-SIMD of the thread form, ladder lengths and dims; one line per case."""
     ws = (0.6, 0.9, 1.1, 1.4, 1.6, 1.9, 2.2, 2.75, 3.5) if held_out else (0.25, 0.5, 0.75, 1.0, 1.25, 1.5, 1.75, 2.0, 2.5, 3.0, 4.0)
-    dims = (18, 22, 26, 38, 46, 54, 62) if held_out else (16, 20, 24, 28, 32, 36, 41, 44, 48, 52, 57, 60, 64)
+    # the fit grid: the dims with a kernel of their own (dim compiled in: 20, 30, 50) and, for all the others, dims across the
+    # generic register widths; held out: other generic dims, and the compiled-in ones at other batch sizes
+    dims = (18, 22, 26, 30, 38, 46, 50, 54, 62) if held_out else (16, 20, 24, 28, 30, 32, 36, 40, 44, 48, 50, 52, 56, 60, 64)
     print(f"{'dim':>4} {'T':>4} {'chains':>7} {'w':>5} {'thread':>10} {'quad':>10} {'auto':>10} {'auto/best':>9}")
     worst = 1.0
     for dim in dims:

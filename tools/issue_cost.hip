@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed) {
         if (OP == FMAMK_F32) asm volatile("v_fmamk_f32 %0, %0, 0x3f800347, %1" : "+v"(f[i]) : "v"(c2));
         if (OP == MAX3_F32) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(c1), "v"(c2));
         if (OP == MED3_F32) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(c1), "v"(c2));
-        if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f[i]) : "v"(c1) : "vcc");
+        if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f[i]) : "v"(c1));  // (vcc: whatever it holds)
         if (OP == XOR_B32) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(u1));
         if (OP == LSHRREV) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a[i]));
         if (OP == CVT_F32_U32) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(f[i]) : "v"(a[i]));
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed) {
         if (OP == CVT_F64_F32) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[i]) : "v"(f[i]));
         if (OP == ADD_F64) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i]) : "v"((double)c1));
         if (OP == FMA_F64) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[i]) : "v"((double)c1), "v"((double)c2));
-        if (OP == CMP_F32) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(f[i]), "v"(c1) : "vcc");
+        if (OP == CMP_F32) asm volatile("v_cmp_lt_f32 s[40:41], %0, %1" : : "v"(f[i]), "v"(c1) : "s40", "s41");
         if (OP == READLANE) asm volatile("v_readlane_b32 %0, %1, 5" : "=s"(sreg) : "v"(a[i]));
         if (OP == WRITELANE) asm volatile("v_writelane_b32 %0, %1, 5" : "+v"(a[i]) : "s"(sreg));
         if (OP == MOV_DPP) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]));

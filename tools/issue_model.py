@@ -110,28 +110,58 @@ def step_path(blocks, order):
     loops = [b for b in order if "This Loop Header: Depth=1" in blocks[b]["notes"]]
     header = max(loops, key=lambda b: sum(o == "v_mad_u64_u32" for o, _ in blocks[b]["ins"]) * 1000 + len(blocks[b]["ins"]))
     in_loop = {b for b in order if f"Header={header.replace('.L', '')}" in blocks[b]["notes"].replace(" ", "")} | {header}
-    best = [None, None]
+    # Among the paths from the header back to itself that avoid the swap event: least penalty, then most VALU work.  The
+    # loop body without its back edge and without inner loops is a DAG: one memoised pass (generic kernels have > 1000 blocks).
+    valu = {b: sum(o.startswith("v_") for o, _ in blocks[b]["ins"]) for b in in_loop}
+    INF = (10**9, 0)
+    memo, visiting = {}, set()
 
-    def dfs(b, path, pen):
-        if best[0] is not None and pen > best[0]:
-            return
+    def cost(t):
+        f = features(blocks[t])
+        return 10 * f["lds"] + 1000 * f["barrier"] + 3 * f["sload"] + 1000 * f["inner"] + 5 * f["global"]
+
+    def best_from(b):
+        """(penalty, -valu, next block) of the best continuation from the END of block b to the header."""
+        if b in memo:
+            return memo[b]
+        if b in visiting:
+            return (INF[0], 0, None)
+        visiting.add(b)
+        out = (INF[0], 0, None)
         for kind, t in blocks[b]["succ"]:
             if kind.startswith("s_cbranch_exec"):
                 continue  # a skip over a block for waves without live lanes: not taken
             if t == header:
-                if best[0] is None or pen < best[0]:
-                    best[0], best[1] = pen, list(path)
+                cand = (0, 0, header)
+            elif t in in_loop:
+                sub = best_from(t)
+                if sub[2] is None:
+                    continue
+                cand = (cost(t) + sub[0], -valu[t] + sub[1], t)
+            else:
                 continue
-            if t not in in_loop or t in path:
-                continue
-            f = features(blocks[t])
-            p = pen + 10 * f["lds"] + 1000 * f["barrier"] + 3 * f["sload"] + 1000 * f["inner"] + 5 * f["global"]
-            dfs(t, path + [t], p)
+            if (cand[0], cand[1]) < (out[0], out[1]):
+                out = cand
+        visiting.discard(b)
+        memo[b] = out
+        return out
 
-    dfs(header, [header], 0)
+    import sys as _sys
+    _sys.setrecursionlimit(20000)
+    best = [None, None]
+    first = best_from(header)
+    if first[2] is not None:
+        path, b = [header], header
+        while True:
+            nxt = best_from(b)[2]
+            if nxt is None or nxt == header:
+                break
+            path.append(nxt)
+            b = nxt
+        best = [(first[0], first[1]), path]
     if best[1] is None:
         sys.exit("no path from the step-loop header back to itself found")
-    return header, best[1], best[0]
+    return header, best[1], best[0][0]
 
 
 def main():
