@@ -96,8 +96,8 @@ __device__ __forceinline__ bool mh_accept(float beta_t, float lp_new, float lp, 
 // stand-alone sweep kernel (capi.hip).  In: this thread's temperature t (0 for idle threads), base = slot of
 // temperature 0 of its ladder, slot = base + t, us = its swap uniform, my_l = its log-density; s_l / s_u = the
 // ladder's published log-densities and uniforms (already synchronised), landed = one int of LDS scratch per slot;
-// par = parity of the event (even/odd order); sync = the group's barrier, all_of = a vote over the group (both called by
-// every thread of the group, or by none).
+// par = parity of the event (even/odd order); sync = the group's barrier (called by every thread of the group, or by
+// none); plain = the group's ladders qualify for the threshold form of the sequential sweep (group-uniform, below).
 // Out: my_l = the log-density that ends up at temperature t, src = the slot whose vector does, pair_acc = pair
 // (t, t+1) accepted (recorded on the thread of temperature t).
 //
@@ -111,18 +111,23 @@ __device__ __forceinline__ bool mh_accept(float beta_t, float lp_new, float lp, 
 // ~22 -> ~6 VALU instructions per pair, 4 % of BASELINE configs[2]'s instructions.  Same decisions up to rounding of the
 // threshold (both forms are within a few ulp of the exact boundary; tests prove every decision that differs from the
 // oracle's literal evaluation).  The reference's corner cases keep its literal rule: if any pair of the group has
-// b_j <= b_k, or any log-density is -inf or NaN (its four-product sum is then NaN and the swap is refused), the whole
-// group takes the literal scan below.
-template <class Sync, class AllOf>
+// b_j <= b_k, or any replica STARTS the launch with a log-density of -inf or NaN (the reference's four-product sum is then
+// NaN and the swap is refused), the whole group takes the literal scan below for the whole launch - `plain`, voted once
+// per launch by swap_threshold_form(): a finite log-density stays finite (the Metropolis rule never accepts a proposal
+// whose log-density is -inf or NaN).
+__device__ __forceinline__ bool swap_threshold_ok(int T, int t, const float *__restrict__ beta, float beta_t, float lp) {
+  return (t >= T - 1 || sub_rn(beta_t, beta[t + 1]) > 0.0f) && lp > kNegInf;  // (NaN compares false)
+}
+
+template <class Sync>
 __device__ __forceinline__ void swap_decide(int T, int t, int base, int slot, int swap_mode, int swap_order, int par,
                                             const float *__restrict__ beta, float beta_t, float us, const float *s_l,
                                             float *s_u, int *landed, float &my_l, int &src, bool &pair_acc, Sync sync,
-                                            AllOf all_of) {
+                                            bool plain) {
   if (swap_order == PTRWM_ORDER_SEQUENTIAL) {
     if (swap_mode == PTRWM_SWAP_EXCHANGE) {
       const bool has_k = t < T - 1;
       const float db = has_k ? sub_rn(beta_t, beta[t + 1]) : 1.0f;
-      const bool plain = all_of(db > 0.0f && my_l > kNegInf);  // (NaN compares false)
       float car_l = s_l[base];
       int car_i = base;
       if (plain) {
@@ -362,6 +367,8 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
   float lp = a.logp[rep];
   const float beta_t = a.beta[t];
   const float tscale = a.temp_scale[t];
+  // one vote per launch: may the group's sequential sweeps take the threshold form?  (swap_decide)
+  const bool swap_plain = group_all(swap_threshold_ok(T, t, a.beta, beta_t, lp));
 
   const unsigned long long gchain = (unsigned long long)(a.chain_offset + chain);
   RngCtx rc;
@@ -483,7 +490,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       s_u[slot] = us;
       sync_group();
       swap_decide(T, t, base, slot, a.swap_mode, a.swap_order, (ev_par0 + swap_in_call) & 1, a.beta, beta_t, us, s_l, s_u,
-                  reinterpret_cast<int *>(s_u + group_threads), my_l, src, pair_acc, sync_group, group_all);
+                  reinterpret_cast<int *>(s_u + group_threads), my_l, src, pair_acc, sync_group, swap_plain);
       if (pair_acc) {
         park[group_threads] += 1;
         park[2 * group_threads] = swap_in_call;

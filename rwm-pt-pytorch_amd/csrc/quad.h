@@ -681,6 +681,9 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
   float lp = a.logp[rep];
   const float beta_t = a.beta[t];
   const float tscale = a.temp_scale[t];
+  // one vote per launch: may the group's sequential sweeps take the threshold form?  (kernel.h swap_decide)
+  const bool swap_plain_here = swap_threshold_ok(T, t, a.beta, beta_t, lp);
+  const bool swap_plain = wide ? (__syncthreads_and(swap_plain_here ? 1 : 0) != 0) : (__builtin_amdgcn_ballot_w64(!swap_plain_here) == 0ull);
 
   const unsigned long long gchain = (unsigned long long)(a.chain_offset + chain);
   RngCtx rc;
@@ -804,23 +807,18 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
         // position, the slot whose vector lands there; a barrier later everyone picks up its own position.  Same
         // decisions, same values: the threshold form of swap_decide (every quad turns its pair's uniform into a threshold
         // on the carried log-density first) or, for ladders it does not cover, the literal scan.
-        const bool has_k = t < T - 1;
-        const float db = has_k ? sub_rn(beta_t, a.beta[t + 1]) : 1.0f;
-        const bool plain = __syncthreads_and((db > 0.0f && my_l > kNegInf) ? 1 : 0) != 0;
-        if (plain) {
-          const float lk = s_l[has_k ? slot_raw + 1 : slot_raw];
-          s_u[slot_raw] = fmaf(-hw_ln(us), __builtin_amdgcn_rcpf(db), lk);  // (the four lanes of a quad write the same value)
-          __syncthreads();
-        }
         if ((int)threadIdx.x < cpw) {  // lane i of the first wavefront scans ladder i of the workgroup
           const int b0 = (int)threadIdx.x * T;
           float car_l = s_l[b0];
           int car_i = b0;
-          if (plain) {
+          if (swap_plain) {
+            // (the scanning lane builds each pair's threshold itself - they do not depend on the carried state, so the
+            // logs and reciprocals of successive pairs overlap - instead of a third barrier to have them published)
 #pragma unroll 4
             for (int j = 0; j < T - 1; ++j) {
               const float lk = s_l[b0 + j + 1];
-              const bool ok = car_l < s_u[b0 + j];
+              const float thr = fmaf(-hw_ln(s_u[b0 + j]), __builtin_amdgcn_rcpf(sub_rn(a.beta[j], a.beta[j + 1])), lk);
+              const bool ok = car_l < thr;
               s_landed[b0 + j] = ok ? b0 + j + 1 : car_i;
               car_l = ok ? car_l : lk;
               car_i = ok ? car_i : b0 + j + 1;
@@ -844,8 +842,7 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
         pair_acc = (t < T - 1) && (src == base + t + 1);
       } else {
         swap_decide(T, t, base, slot, a.swap_mode, a.swap_order, (ev_par0 + swap_in_call) & 1, a.beta, beta_t, us, s_l, s_u,
-                    s_landed, my_l, src, pair_acc, sync_group,
-                    [&](bool p) -> bool { return wide ? (__syncthreads_and(p ? 1 : 0) != 0) : (__builtin_amdgcn_ballot_w64(!p) == 0ull); });
+                    s_landed, my_l, src, pair_acc, sync_group, swap_plain);
       }
       if (pair_acc) {
         n_swap_acc += 1;

@@ -14,13 +14,16 @@
 enum Op {
   ADD_F32, MUL_F32, FMA_F32, FMAMK_F32, MAX3_F32, MED3_F32, CNDMASK, XOR_B32, LSHRREV, CVT_F32_U32, AND_OR, ADD_U32, BITOP3,
   MAD_U64_U32, MUL_LO_U32, EXP_F32, LOG_F32, SQRT_F32, SIN_F32, COS_F32, RCP_F32, CVT_F64_F32, ADD_F64, FMA_F64, CMP_F32,
-  READLANE, WRITELANE, MOV_DPP, DS_READ_B32, DS_WRITE_B32, DS_READ_B128, N_OPS
+  READLANE, WRITELANE, MOV_DPP, DS_READ_B32, DS_WRITE_B32, DS_READ_B128,
+  // mixes (per GROUP of four instructions, not per instruction): do instruction classes overlap on the SIMD?
+  MIX_EXP_FMA3, MIX_MAD_BITOP_FMA2, MIX_EXP_MAD_BITOP_FMA, N_OPS
 };
 static const char *kNames[N_OPS] = {
   "v_add_f32", "v_mul_f32", "v_fma_f32", "v_fmamk_f32", "v_max3_f32", "v_med3_f32", "v_cndmask_b32", "v_xor_b32",
   "v_lshrrev_b32", "v_cvt_f32_u32", "v_and_or_b32", "v_add_u32", "v_bitop3_b32", "v_mad_u64_u32", "v_mul_lo_u32",
   "v_exp_f32", "v_log_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32", "v_rcp_f32", "v_cvt_f64_f32", "v_add_f64", "v_fma_f64",
-  "v_cmp_lt_f32", "v_readlane_b32", "v_writelane_b32", "v_mov_b32_dpp", "ds_read_b32", "ds_write_b32", "ds_read_b128"};
+  "v_cmp_lt_f32", "v_readlane_b32", "v_writelane_b32", "v_mov_b32_dpp", "ds_read_b32", "ds_write_b32", "ds_read_b128",
+  "mix:v_exp_f32+3*v_fma_f32", "mix:v_mad_u64_u32+v_bitop3_b32+2*v_fma_f32", "mix:v_exp_f32+v_mad_u64_u32+v_bitop3_b32+v_fma_f32"};
 
 template <int OP>
 __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed) {
@@ -82,6 +85,27 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed) {
         if (OP == DS_READ_B32) asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(f[i]) : "v"((uint32_t)(threadIdx.x * 4)));
         if (OP == DS_WRITE_B32) asm volatile("ds_write_b32 %0, %1" : : "v"((uint32_t)(threadIdx.x * 4)), "v"(f[i]) : "memory");
         if (OP == DS_READ_B128) asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(q4) : "v"((uint32_t)(threadIdx.x * 16)));
+        // mixes: one GROUP of four independent instructions per slot (a quarter as many groups: i < 2 only)
+        if (OP == MIX_EXP_FMA3 && i < 2) {
+          asm volatile("v_exp_f32 %0, %0" : "+v"(f[i]));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i + 2]) : "v"(c1), "v"(c2));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i + 4]) : "v"(c1), "v"(c2));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i + 6]) : "v"(c1), "v"(c2));
+        }
+        if (OP == MIX_MAD_BITOP_FMA2 && i < 2) {
+          asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p[i]) : "s"(0xD2511F53u), "v"(a[i]) : "vcc");
+          asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a[i + 2]) : "v"(u1), "s"(sreg));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i + 4]) : "v"(c1), "v"(c2));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i + 6]) : "v"(c1), "v"(c2));
+          a[i] = (uint32_t)p[i];
+        }
+        if (OP == MIX_EXP_MAD_BITOP_FMA && i < 2) {
+          asm volatile("v_exp_f32 %0, %0" : "+v"(f[i]));
+          asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p[i]) : "s"(0xD2511F53u), "v"(a[i]) : "vcc");
+          asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a[i + 2]) : "v"(u1), "s"(sreg));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i + 6]) : "v"(c1), "v"(c2));
+          a[i] = (uint32_t)p[i];
+        }
       }
     }
   }
