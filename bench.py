@@ -404,7 +404,8 @@ def main():
             with open(imf) as f:
                 im = json.load(f)
             roof["issue_cost_weighted"] = {
-                "frac": im.get("issue_cost_weighted"), "busy_ns_per_wave_step": im.get("busy_ns_per_wave_step"),
+                "frac": im.get("issue_cost_weighted"), "sum_of_standalone_costs_over_measured": im.get("sum_of_standalone_costs_over_measured"),
+                "busy_ns_per_wave_step": im.get("busy_ns_per_wave_step_in_context") or im.get("busy_ns_per_wave_step"),
                 "ns_per_wave_step": im.get("ns_per_wave_step"), "valu_on_step_path": im.get("valu_on_path"),
                 "pmc_check": im.get("pmc_check"), "source": "profiles/r03_issue_model.txt (tools/issue_model.py, tools/issue_cost.hip)",
                 "model_of_this_build": im.get("lib_sha256") == lib_sha}

@@ -86,7 +86,13 @@ template <int DP>
 __device__ __forceinline__ float philox_normal_step(float (&y)[DP], const float (&x)[DP], int D, float tscale,
                                                     const RngCtx &rc) {
   constexpr int NB = (2 * ((DP + 1) / 2)) / 4 + 1;  // blocks up to the one holding word 2*ceil(DP/2)
+#ifdef PTRWM_INJECT_ACCEPT_WORD_SLIP
+  // FAULT INJECTION (tools/inject_slip_check.sh only, never in a shipped build): the accept uniform is taken one pair
+  // early - the radius word of the last Box-Muller pair - so the Philox-mode parity tests can be shown to fail on it
+  const int w_a = 2 * ((D + 1) >> 1) - 2;
+#else
   const int w_a = 2 * ((D + 1) >> 1);
+#endif
   float u_acc = 0.0f;
 #pragma unroll
   for (int c = 0; c < NB; ++c) {

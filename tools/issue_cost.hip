@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed) {
   lds[threadIdx.x] = f[0];
   __syncthreads();
   uint32_t sreg = seed;
+  const uint64_t lane_mask = 0x5555555555555555ull ^ seed;
   typedef float vec4 __attribute__((ext_vector_type(4)));
   vec4 q4 = {0, 0, 0, 0};
   for (int it = 0; it < ITERS; ++it) {
@@ -57,7 +58,7 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed) {
         if (OP == FMAMK_F32) asm volatile("v_fmamk_f32 %0, %0, 0x3f800347, %1" : "+v"(f[i]) : "v"(c2));
         if (OP == MAX3_F32) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(c1), "v"(c2));
         if (OP == MED3_F32) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(c1), "v"(c2));
-        if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f[i]) : "v"(c1));  // (vcc: whatever it holds)
+        if (OP == CNDMASK) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(f[i]) : "v"(c1), "s"(lane_mask));  // an SGPR-pair mask, as the kernels use
         if (OP == XOR_B32) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(u1));
         if (OP == LSHRREV) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a[i]));
         if (OP == CVT_F32_U32) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(f[i]) : "v"(a[i]));

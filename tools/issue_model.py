@@ -221,21 +221,40 @@ def main():
         if ns is not None:
             busy += c * ns
         rows.append((o, c, ns))
+    # Philox in context.  v_mad_u64_u32 and v_bitop3_b32 timed alone run slower than the same pair issued among full-rate
+    # float work of other waves (tools/issue_cost.hip "mix:" probes) - and in the kernel they always are: four waves share
+    # a SIMD and three quarters of their instructions are plain fp32.  The in-context price of a (mad, bitop3) pair is the
+    # mix of one of each with two fmas, minus the two fmas.
+    busy_ctx = None
+    mixk = "mix:v_mad_u64_u32+v_bitop3_b32+2*v_fma_f32"
+    if costs and mixk in costs:
+        pair_alone = costs["v_mad_u64_u32"] + costs["v_bitop3_b32"]
+        pair_ctx = 4 * costs[mixk] - 2 * costs["v_fma_f32"]
+        n_pairs = min(ops.get("v_mad_u64_u32", 0), ops.get("v_bitop3_b32", 0))
+        busy_ctx = busy - n_pairs * (pair_alone - pair_ctx)
     if costs:
         print(f"\n{'opcode':24s} {'count':>6s} {'ns each':>8s} {'ns':>9s} {'share':>6s}")
         for o, c, ns in rows:
             print(f"{o:24s} {c:6d} {ns:8.3f} {c * ns:9.1f} {c * ns / busy:6.1%}")
         print(f"busy SIMD time per wave-step (sum of VALU count x measured issue cost): {busy:.1f} ns"
               + (f"; unpriced opcodes priced as v_fma_f32: {unpriced}" if unpriced else ""))
+        if busy_ctx is not None:
+            print(f"the same with the Philox pairs at their in-context price ({n_pairs} x ({pair_ctx:.3f} instead of {pair_alone:.3f}) ns): "
+                  f"{busy_ctx:.1f} ns")
         if a.ns_per_wave_step:
-            print(f"measured SIMD time per wave-step: {a.ns_per_wave_step:.1f} ns  ->  cost-weighted issue fraction "
-                  f"{busy / a.ns_per_wave_step:.3f}")
+            print(f"measured SIMD time per wave-step: {a.ns_per_wave_step:.1f} ns  ->  sum of stand-alone costs / measured = "
+                  f"{busy / a.ns_per_wave_step:.3f}" + (f"; with in-context Philox price = {busy_ctx / a.ns_per_wave_step:.3f} "
+                  "(the cost-weighted issue fraction: how much of the step's SIMD time its own instructions account for)"
+                  if busy_ctx is not None else ""))
     if a.json:
         json.dump({"kernel": name, "path": path, "valu_on_path": valu, "salu_on_path": salu, "histogram": dict(ops),
                    "busy_ns_per_wave_step": busy if costs else None, "unpriced": unpriced,
                    "pmc_check": {"valu_per_wave_step": a.valu_per_wave_step, "salu_per_wave_step": a.salu_per_wave_step, "ok": ok},
                    "ns_per_wave_step": a.ns_per_wave_step,
-                   "issue_cost_weighted": (busy / a.ns_per_wave_step) if (costs and a.ns_per_wave_step) else None,
+                   "sum_of_standalone_costs_over_measured": (busy / a.ns_per_wave_step) if (costs and a.ns_per_wave_step) else None,
+                   "busy_ns_per_wave_step_in_context": busy_ctx,
+                   "issue_cost_weighted": ((busy_ctx if busy_ctx is not None else busy) / a.ns_per_wave_step)
+                   if (costs and a.ns_per_wave_step) else None,
                    "costs": os.path.relpath(a.costs, ROOT), "waves": a.waves, "lib_sha256": lib_sha}, open(a.json, "w"), indent=1)
     sys.exit(0 if ok else 1)
 
