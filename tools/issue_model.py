@@ -196,7 +196,8 @@ def main():
         for o, _ in blocks[b]["ins"]:
             ops[strip(o)] += 1
     valu = sum(c for o, c in ops.items() if o.startswith("v_"))
-    salu = sum(c for o, c in ops.items() if o.startswith("s_") and not o.startswith(("s_waitcnt", "s_nop", "s_load", "s_buffer")))
+    # (SQ_INSTS_SALU does not count branches, waits, nops or scalar loads)
+    salu = sum(c for o, c in ops.items() if o.startswith("s_") and not o.startswith(("s_waitcnt", "s_nop", "s_load", "s_buffer", "s_cbranch", "s_branch", "s_barrier")))
     smem = sum(c for o, c in ops.items() if o.startswith(("s_load", "s_buffer")))
     print(f"kernel {name}\nstep loop header {header}; path of a step without a swap event: {' '.join(path)} (penalty {pen})")
     print(f"instructions on the path: {sum(ops.values())} = {valu} VALU + {salu} SALU + {smem} scalar loads + "

@@ -10,7 +10,9 @@ TAG=${1:-r03}
 OUT=/root/repo/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 # per-opcode issue costs on this box (tools/issue_cost.hip), the price list of tools/issue_model.py
-if [ -x /root/repo/tools/issue_cost ]; then /root/repo/tools/issue_cost > /root/repo/profiles/${TAG}_issue_costs.json 2> "$OUT/issue_cost.err" || true; fi
+# (raw copy under $OUT: gpurun brings gpurun_out/ home, not profiles/ - tools/profile_summary.py and tools/issue_model.py are
+# then re-run at home on the raw output and write the same files under profiles/)
+if [ -x /root/repo/tools/issue_cost ]; then /root/repo/tools/issue_cost > "$OUT/issue_costs.json" 2> "$OUT/issue_cost.err" && cp "$OUT/issue_costs.json" /root/repo/profiles/${TAG}_issue_costs.json; fi
 cd /tmp
 export TMPDIR=/tmp
 B="python3 /root/repo/bench.py --cpu-seconds 0 --no-extras"
