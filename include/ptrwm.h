@@ -237,7 +237,9 @@ int32_t ptrwm_swap_sweep(const ptrwm_run_args *args, int32_t dim, int64_t event_
  *      swap step, the swap event (ext_swap_u [n_chains, n_temps-1] of THIS event in external-randoms mode) - exactly
  *      what ptrwm_run does for the step.  Reads from `args`: everything ptrwm_run reads except n_steps and the
  *      trace fields (accept_flags, if set, is [n_chains, n_temps] for this step).
- * `proposals` [n_chains, n_temps, dim] and `accept_u` [n_chains, n_temps] are device scratch owned by the caller;
+ * `proposals` [n_chains, n_temps, dim] and `accept_u` [2, n_chains, n_temps] are device scratch owned by the caller
+ * (accept_u plane 0: the accept uniforms; plane 1: the squared length of the increment as the fused kernel counts it -
+ * the Philox paths of the Normal and UniformRadius proposals know it without a pass over the dimensions - or -1);
  * after ptrwm_split_accept `proposals` holds the states from before the step.  Driven with ptrwm_logdensity as the
  * density, a split step reproduces ptrwm_run bit for bit (tests/test_gpu_engine_parity.py). */
 int32_t ptrwm_split_propose(const ptrwm_proposal_desc *proposal, const ptrwm_run_args *args, int32_t dim,

@@ -384,7 +384,9 @@ __global__ void __launch_bounds__(256) split_accept_kernel(const SplitAcceptArgs
       y[d] = xo;
     }
   }
-  const float j2 = tree4_add(j2p);
+  // (the proposal's own squared jump when ptrwm_split_propose recorded one: second plane of accept_u, kernel.h)
+  const float given = a.accept_u[a.n_reps + i];
+  const float j2 = given >= 0.0f ? given : tree4_add(j2p);
   if (acc) a.logp[i] = lp_new;
   if (a.accept_flags != nullptr) a.accept_flags[i] = acc ? 1 : 0;
   if (a.count_on) {

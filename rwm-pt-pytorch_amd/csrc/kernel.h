@@ -421,7 +421,10 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       }
     }
 
-    const float u_acc = Proposal::propose(y, x, fresh_dim<EXACT>(D0), tscale, a.pp, rc, ext_raw, ext_u);
+    constexpr int W = canon_width(DP);
+    float jump = 0.0f;  // the squared length of the increment, if the proposal knows it (proposals.h)
+    int jump_kind;      // (a constant in production kernels)
+    const float u_acc = Proposal::propose(y, x, fresh_dim<EXACT>(D0), tscale, a.pp, rc, ext_raw, ext_u, jump, jump_kind);
     const float lp_new = Target::template logp<false>(y, fresh_dim<EXACT>(D0), a.tp);
     const int D = fresh_dim<EXACT>(D0);
 
@@ -434,9 +437,16 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     }
 
     float j2;
-    constexpr int W = canon_width(DP);
-    float j2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // squared jump in the canonical four-range order (philox.h)
-    if (!swap_due) {
+    if (!swap_due && jump_kind != kJumpNone) {
+      // the proposal knows the length of its own increment: the move itself is one select per dimension
+      PTRWM_DIM_LOOP(d, DP, D, {
+        x[d] = acc ? y[d] : x[d];
+        if ((d & PTRWM_J2_FENCE_MASK) == PTRWM_J2_FENCE_MASK) sched_fence_soft();
+      })
+      j2 = acc ? jump : 0.0f;
+      lp = lp_mh;
+    } else if (!swap_due) {
+      float j2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // squared jump in the canonical four-range order (philox.h)
 #ifdef PTRWM_J2_SEPARATE
 #pragma unroll
       for (int d = 0; d < DP; ++d) {
@@ -498,6 +508,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       // commit MH move and swap in one pass: every thread publishes its post-MH vector as its slab row, then
       // fetches the row of slot `src` (rows exchanged through LDS: 2 LDS ops per dimension, no HBM)
       {
+        float j2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // (a swap step's jump is taken from the rows, in the canonical order)
         float *my_row = rows + slot * D;
         PTRWM_DIM_LOOP(d, DP, D, { my_row[d] = acc ? y[d] : x[d]; })
         sync_group();
@@ -630,7 +641,9 @@ __global__ void __launch_bounds__(kBlockThreads, standalone_min_waves(DP)) ptrwm
   rc.k0 = k0;
   rc.k1 = k1;
   const float *er = ext_raw != nullptr ? ext_raw + i * n_raw_ext : nullptr;
-  Proposal::propose(y, x, D, temp_scale[t], pp, rc, er, 0.0f);
+  float jump = 0.0f;
+  int jump_kind;
+  Proposal::propose(y, x, D, temp_scale[t], pp, rc, er, 0.0f, jump, jump_kind);
   float *__restrict__ op = out + i * D;
 #pragma unroll
   for (int d = 0; d < DP; ++d)
@@ -662,12 +675,17 @@ __global__ void __launch_bounds__(kBlockThreads, standalone_min_waves(DP)) ptrwm
   rc.k0 = k0;
   rc.k1 = k1;
   const float *er = ext_raw != nullptr ? ext_raw + i * n_raw_ext : nullptr;
-  const float u = Proposal::propose(y, x, D, temp_scale[t], pp, rc, er, ext_u != nullptr ? ext_u[i] : 0.0f);
+  float jump = 0.0f;
+  int jump_kind;
+  const float u = Proposal::propose(y, x, D, temp_scale[t], pp, rc, er, ext_u != nullptr ? ext_u[i] : 0.0f, jump, jump_kind);
   float *__restrict__ op = proposals + i * D;
 #pragma unroll
   for (int d = 0; d < DP; ++d)
     if (d < D) op[d] = y[d];
   accept_u[i] = u;
+  // second plane of the scratch array: the proposal's own squared jump, exactly as the fused kernel counts it, or -1 when
+  // it is to be taken from the states (external randoms, Laplace): split_accept_kernel then reproduces ptrwm_run's sums
+  accept_u[n_chains * T + i] = jump_kind == kJumpTotal ? jump : -1.0f;
 }
 
 }  // namespace ptrwm

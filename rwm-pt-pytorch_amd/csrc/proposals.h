@@ -21,6 +21,15 @@ struct RngCtx {
   uint32_t c0hi, c1, c2, c3, k0, k1;
 };
 
+// What a proposal functor says about the squared length of the increment it just made (the Metropolis step's squared jump
+// when the proposal is accepted).  The Philox paths know it without looking at y - x: a Box-Muller pair contributes
+// rad^2 (sin^2 + cos^2) = the very argument of its square root, and a UniformRadius increment has length r by
+// construction.  kJumpNone: compute it from the states (external randoms, Laplace).  kJumpTotal: `jump` is the squared
+// jump (sums over Box-Muller pairs are taken in the canonical four-range order, philox.h, and combined before the functor
+// returns - one live register across the density evaluation, not four).  kJumpPartial (lane-split form only): `jump` is
+// this lane's range, to be combined across the quad by the caller.
+enum { kJumpNone = 0, kJumpPartial = 1, kJumpTotal = 2 };
+
 struct PParams {
   const float *__restrict__ dim_scale;  // [D] Laplace, wave-uniform
   float inv_dim;
@@ -82,9 +91,16 @@ __device__ __forceinline__ void philox_normals(float (&z)[DP], int D, const RngC
 // into the Box-Muller radius (one multiply per pair instead of one per dimension) and the add is an fma.
 // Differs from "z, then z * scale, then x + inc" by <= 1 ulp of y, below the hardware sin/cos error; the
 // external-randoms path keeps the reference's exact two-op form.
+// The squared jump comes with it: rad^2 of every pair both of whose dimensions exist - which is c_t log2(u), the argument of
+// the pair's square root, with c_t = -2 ln 2 tscale^2 folded once per step - summed per canonical range (a pair never
+// straddles two ranges: W is even); the last dimension of an odd dim contributes (rad sin)^2.  One add per pair instead of
+// a subtraction and an fma per dimension; within 1e-6 relative of |y - x|^2 (the rounding of x + inc and of sin^2 + cos^2).
 template <int DP>
 __device__ __forceinline__ float philox_normal_step(float (&y)[DP], const float (&x)[DP], int D, float tscale,
-                                                    const RngCtx &rc) {
+                                                    const RngCtx &rc, float &jump_total) {
+  constexpr int W = canon_width(DP);
+  float jump[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const float c_t = mul_rn(mul_rn(-2.0f * kLn2, tscale), tscale);
   constexpr int NB = (2 * ((DP + 1) / 2)) / 4 + 1;  // blocks up to the one holding word 2*ceil(DP/2)
 #ifdef PTRWM_INJECT_ACCEPT_WORD_SLIP
   // FAULT INJECTION (tools/inject_slip_check.sh only, never in a shipped build): the accept uniform is taken one pair
@@ -103,10 +119,12 @@ __device__ __forceinline__ float philox_normal_step(float (&y)[DP], const float 
       for (int h = 0; h < 2; ++h) {
         const int d = (4 * c + 2 * h + 1 < DP) ? 4 * c + 2 * h : 0;
         const uint32_t ra = h ? r.z : r.x, rb = h ? r.w : r.y;
-        const float rad = tscale * hw_sqrt(bm_radius_sq(ra));
+        const float arg = mul_rn(c_t, hw_log2(u01_open0(ra)));
+        const float rad = hw_sqrt(arg);
         const float ang = bm_turns(rb);
         y[d] = fmaf(rad, __builtin_amdgcn_sinf(ang), x[d]);
         y[d + 1] = fmaf(rad, __builtin_amdgcn_cosf(ang), x[d + 1]);
+        jump[d / W] = add_rn(jump[d / W], arg);
       }
       sched_fence();
     } else if (4 * c <= w_a) {
@@ -116,17 +134,26 @@ __device__ __forceinline__ float philox_normal_step(float (&y)[DP], const float 
         const int d = 4 * c + 2 * h;
         const uint32_t ra = h ? r.z : r.x, rb = h ? r.w : r.y;
         if (d < DP && d < D) {
-          const float rad = tscale * hw_sqrt(bm_radius_sq(ra));
+          const float arg = mul_rn(c_t, hw_log2(u01_open0(ra)));
+          const float rad = hw_sqrt(arg);
           const float ang = bm_turns(rb);
           const int d0 = d < DP ? d : 0, d1 = d + 1 < DP ? d + 1 : 0;
-          y[d0] = fmaf(rad, __builtin_amdgcn_sinf(ang), x[d0]);
-          if (d + 1 < DP && d + 1 < D) y[d1] = fmaf(rad, __builtin_amdgcn_cosf(ang), x[d1]);
+          const float sn = __builtin_amdgcn_sinf(ang);
+          y[d0] = fmaf(rad, sn, x[d0]);
+          if (d + 1 < DP && d + 1 < D) {
+            y[d1] = fmaf(rad, __builtin_amdgcn_cosf(ang), x[d1]);
+            jump[d0 / W] = add_rn(jump[d0 / W], arg);
+          } else {
+            const float i0 = mul_rn(rad, sn);  // the last dimension of an odd dim: half a pair
+            jump[d0 / W] = fmaf(i0, i0, jump[d0 / W]);
+          }
         }
         if (d == w_a) u_acc = u01(ra);
       }
       sched_fence();
     }
   }
+  jump_total = tree4_add(jump);
   return u_acc;
 }
 
@@ -137,14 +164,16 @@ struct NormalProposal {
   static constexpr int kKind = PTRWM_PROPOSAL_NORMAL;
   __device__ __forceinline__ static float propose(float (&y)[DP], const float (&x)[DP], int D,
                                                   float tscale, const PParams &, const RngCtx &rc,
-                                                  const float *ext_raw, float ext_u) {
+                                                  const float *ext_raw, float ext_u, float &jump, int &jump_kind) {
     float u_acc = ext_u;
     if (ext_raw != nullptr) {
+      jump_kind = kJumpNone;
 #pragma unroll
       for (int d = 0; d < DP; ++d)
         if (d < D) y[d] = add_rn(x[d], mul_rn(ext_raw[d], tscale));
     } else {
-      u_acc = philox_normal_step<DP>(y, x, D, tscale, rc);
+      jump_kind = kJumpTotal;
+      u_acc = philox_normal_step<DP>(y, x, D, tscale, rc, jump);
     }
     return u_acc;
   }
@@ -170,8 +199,9 @@ struct LaplaceProposal {
   }
   __device__ __forceinline__ static float propose(float (&y)[DP], const float (&x)[DP], int D,
                                                   float tscale, const PParams &pp, const RngCtx &rc,
-                                                  const float *ext_raw, float ext_u) {
+                                                  const float *ext_raw, float ext_u, float &, int &jump_kind) {
     float u_acc = ext_u;
+    jump_kind = kJumpNone;
     const const_float_ptr dsc = uniform_vec(pp.dim_scale);
     if (ext_raw != nullptr) {
 #pragma unroll
@@ -216,7 +246,7 @@ struct UniformRadiusProposal {
   static constexpr int kKind = PTRWM_PROPOSAL_UNIFORM_RADIUS;
   __device__ __forceinline__ static float propose(float (&y)[DP], const float (&x)[DP], int D,
                                                   float tscale, const PParams &pp, const RngCtx &rc,
-                                                  const float *ext_raw, float ext_u) {
+                                                  const float *ext_raw, float ext_u, float &jump, int &jump_kind) {
     float u_acc = ext_u, u_rad;
     if (ext_raw != nullptr) {
 #pragma unroll
@@ -232,7 +262,8 @@ struct UniformRadiusProposal {
     constexpr int W = canon_width(DP);
     float n2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // |g|^2 in the canonical four-range order (philox.h)
     PTRWM_DIM_LOOP(d, DP, D, { n2p[d / W] = fmaf(y[d], y[d], n2p[d / W]); })
-    const float nrm = hw_sqrt(tree4_add(n2p));
+    const float nrm_sq = tree4_add(n2p);
+    const float nrm = hw_sqrt(nrm_sq);
     const float safe = nrm > 1e-12f ? nrm : 1.0f;
     const float rad = tscale * hw_exp2(pp.inv_dim * hw_log2(u_rad));
     // g / n as g * (1/n) with one IEEE reciprocal per step: <= 1.5 ulp from the reference's per-element division
@@ -242,6 +273,7 @@ struct UniformRadiusProposal {
     // optimiser merges them into one with a selected INDEX, which moves y[] to scratch (tools/kernel_stats.py --check)
     if (ext_raw != nullptr) {
       // external randoms: the reference's own operation order, (g / n) * r, then x + increment (uniform.py:58-73)
+      jump_kind = kJumpNone;
 #pragma unroll
       for (int d = 0; d < DP; ++d)
         if (d < D) y[d] = add_rn(x[d], mul_rn(mul_rn(y[d], inv), rad));
@@ -253,6 +285,9 @@ struct UniformRadiusProposal {
 #pragma unroll
       for (int d = 0; d < DP; ++d)
         if (d < D) y[d] = fmaf(y[d], k, x[d]);
+      // |g k|^2 = |g|^2 k^2: the squared jump without another pass over the dimensions
+      jump_kind = kJumpTotal;
+      jump = mul_rn(mul_rn(nrm_sq, k), k);
     }
     return u_acc;
   }

@@ -98,15 +98,20 @@ __device__ __forceinline__ bool q_valid(const QLane &l, int j) {
 template <int W, int MIN_OWN>
 struct QNormal {
   static constexpr int kKind = PTRWM_PROPOSAL_NORMAL;
+  // jump / jump_kind: proposals.h (this lane's range of the squared jump: kJumpPartial sums are combined by the caller)
   __device__ __forceinline__ static float propose(float (&y)[W], const float (&x)[W], const QLane &l, int D, float tscale,
-                                                  const PParams &, const RngCtx &rc, const float *ext_rep, float ext_u) {
+                                                  const PParams &, const RngCtx &rc, const float *ext_rep, float ext_u,
+                                                  float &jump, int &jump_kind) {
     if (ext_rep != nullptr) {
+      jump_kind = kJumpNone;
       const float *er = ext_rep + l.d0;
 #pragma unroll
       for (int j = 0; j < W; ++j)
         if (q_valid<MIN_OWN>(l, j)) y[j] = add_rn(x[j], mul_rn(er[j], tscale));
       return ext_u;
     }
+    jump_kind = kJumpPartial;
+    const float c_t = mul_rn(mul_rn(-2.0f * kLn2, tscale), tscale);
     const int w_a = 2 * ((D + 1) >> 1);  // accept word
     const int c_a = w_a >> 2;            // its block (uniform)
     const uint32_t cb0 = (uint32_t)(l.q * (W / 4));
@@ -121,10 +126,18 @@ struct QNormal {
           const int j = 4 * b + 2 * h;
           const uint32_t ra = h ? r.z : r.x, rb = h ? r.w : r.y;
           if (q_valid<MIN_OWN>(l, j)) {
-            const float rad = tscale * hw_sqrt(bm_radius_sq(ra));
+            const float arg = mul_rn(c_t, hw_log2(u01_open0(ra)));
+            const float rad = hw_sqrt(arg);
             const float ang = bm_turns(rb);
-            y[j] = fmaf(rad, __builtin_amdgcn_sinf(ang), x[j]);
-            if (q_valid<MIN_OWN>(l, j + 1)) y[j + 1] = fmaf(rad, __builtin_amdgcn_cosf(ang), x[j + 1]);
+            const float sn = __builtin_amdgcn_sinf(ang);
+            y[j] = fmaf(rad, sn, x[j]);
+            if (q_valid<MIN_OWN>(l, j + 1)) {
+              y[j + 1] = fmaf(rad, __builtin_amdgcn_cosf(ang), x[j + 1]);
+              jump = add_rn(jump, arg);
+            } else {
+              const float i0 = mul_rn(rad, sn);  // the last dimension of an odd dim: half a pair
+              jump = fmaf(i0, i0, jump);
+            }
           }
           if ((int)(4 * cb) + 2 * h == w_a) u_loc = u01(ra);
         }
@@ -143,7 +156,9 @@ template <int W, int MIN_OWN>
 struct QLaplace {
   static constexpr int kKind = PTRWM_PROPOSAL_LAPLACE;
   __device__ __forceinline__ static float propose(float (&y)[W], const float (&x)[W], const QLane &l, int D, float tscale,
-                                                  const PParams &pp, const RngCtx &rc, const float *ext_rep, float ext_u) {
+                                                  const PParams &pp, const RngCtx &rc, const float *ext_rep, float ext_u,
+                                                  float &, int &jump_kind) {
+    jump_kind = kJumpNone;
     const float *dsc = pp.dim_scale + l.d0;  // this lane's per-dimension scales (L1-resident; lane-dependent address)
     if (ext_rep != nullptr) {
       const float *er = ext_rep + l.d0;
@@ -183,7 +198,8 @@ template <int W, int MIN_OWN>
 struct QUniformRadius {
   static constexpr int kKind = PTRWM_PROPOSAL_UNIFORM_RADIUS;
   __device__ __forceinline__ static float propose(float (&y)[W], const float (&x)[W], const QLane &l, int D, float tscale,
-                                                  const PParams &pp, const RngCtx &rc, const float *ext_rep, float ext_u) {
+                                                  const PParams &pp, const RngCtx &rc, const float *ext_rep, float ext_u,
+                                                  float &jump, int &jump_kind) {
     float u_acc = ext_u, u_rad;
     if (ext_rep != nullptr) {
       const float *er = ext_rep + l.d0;
@@ -232,11 +248,13 @@ struct QUniformRadius {
 #pragma unroll
     for (int j = 0; j < W; ++j)
       if (q_valid<MIN_OWN>(l, j)) n2 = fmaf(y[j], y[j], n2);
-    const float nrm = hw_sqrt(quad_tree_add(n2));
+    const float nrm_sq = quad_tree_add(n2);
+    const float nrm = hw_sqrt(nrm_sq);
     const float safe = nrm > 1e-12f ? nrm : 1.0f;
     const float rad = tscale * hw_exp2(pp.inv_dim * hw_log2(u_rad));
     const float inv = div_rn(1.0f, safe);
     if (ext_rep != nullptr) {
+      jump_kind = kJumpNone;
 #pragma unroll
       for (int j = 0; j < W; ++j)
         if (q_valid<MIN_OWN>(l, j)) y[j] = add_rn(x[j], mul_rn(mul_rn(y[j], inv), rad));
@@ -245,6 +263,8 @@ struct QUniformRadius {
 #pragma unroll
       for (int j = 0; j < W; ++j)
         if (q_valid<MIN_OWN>(l, j)) y[j] = fmaf(y[j], k, x[j]);
+      jump_kind = kJumpTotal;  // |g k|^2 = |g|^2 k^2, the same bits on all four lanes
+      jump = mul_rn(mul_rn(nrm_sq, k), k);
     }
     return u_acc;
   }
@@ -258,23 +278,17 @@ struct QRoughCarpetT {
   static constexpr int kKind = PTRWM_TARGET_ROUGH_CARPET;
   template <bool SCALED>
   __device__ __forceinline__ static float impl(const float (&y)[W], const QLane &l, const TParams &tp) {
-    const float m0 = tp.p[0], m1 = tp.p[1], m2 = tp.p[2];
+    const float m0 = -(tp.p[0] * kRcScale), m1 = -(tp.p[1] * kRcScale), m2 = -(tp.p[2] * kRcScale);  // (targets.h)
     [[maybe_unused]] const float *sc_v = SCALED ? tp.vec0 + l.d0 : nullptr;
     const float w0 = tp.p[3] * kLog2e, w1 = tp.p[4] * kLog2e, w2 = tp.p[5] * kLog2e;
-    const float nh = -0.5f * kLog2e;
     float sm = 0.0f, pr = 1.0f;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
       if (q_valid<MIN_OWN>(l, j)) {
-        float d0, d1, d2;
-        if constexpr (SCALED) {
-          const float sc = sc_v[j];
-          d0 = fmaf(y[j], sc, -m0), d1 = fmaf(y[j], sc, -m1), d2 = fmaf(y[j], sc, -m2);
-        } else {
-          d0 = y[j] - m0, d1 = y[j] - m1, d2 = y[j] - m2;
-        }
+        const float sc = SCALED ? sc_v[j] * kRcScale : kRcScale;
+        const float d0 = fmaf(y[j], sc, m0), d1 = fmaf(y[j], sc, m1), d2 = fmaf(y[j], sc, m2);
         float mx, s;
-        rc_dim_term<false, TWO_TERM>(d0, d1, d2, nh, w0, w1, w2, mx, s);
+        rc_dim_term<false, TWO_TERM>(d0, d1, d2, w0, w1, w2, mx, s);
         sm = add_rn(sm, mx);
         pr = mul_rn(pr, s);
       }
@@ -729,8 +743,11 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
     }
 
     float u_acc;
+    float jump = 0.0f;  // this lane's range of the squared jump, if the proposal provides it (proposals.h)
+    int jump_kind = kJumpNone;
     if constexpr (!F64) {
-      u_acc = Proposal::propose(y, x, l, D, tscale, a.pp, rc, ext_rep, ext_u);
+      u_acc = Proposal::propose(y, x, l, D, tscale, a.pp, rc, ext_rep, ext_u, jump, jump_kind);
+      if (jump_kind == kJumpPartial) jump = quad_tree_add(jump);  // the canonical combination, now: one live register
     } else {
       if (ext_rep != nullptr) {
         // the reference's float64 path: increments = bmm(diag(scale).double(), randn(float64)); proposals = states +
@@ -746,7 +763,9 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
         float zero[W];
 #pragma unroll
         for (int j = 0; j < W; ++j) zero[j] = 0.0f;
-        u_acc = Proposal::propose(y, zero, l, D, tscale, a.pp, rc, nullptr, 0.0f);
+        float jump64 = 0.0f;  // (double states take their jump from the states themselves)
+        int kind64;
+        u_acc = Proposal::propose(y, zero, l, D, tscale, a.pp, rc, nullptr, 0.0f, jump64, kind64);
 #pragma unroll
         for (int j = 0; j < W; ++j)
           if (q_valid<MIN_OWN>(l, j)) yd[j] = dadd_rn(x[j], (double)y[j]);
@@ -764,7 +783,14 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
 
     state_t j2l = 0;  // this lane's range of the squared jump
     state_t j2;
-    if (!swap_due) {
+    if (!swap_due && jump_kind != kJumpNone) {
+      // (float states only) the proposal knows the length of its own increment: the move is one select per dimension
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+        if (q_valid<MIN_OWN>(l, j)) x[j] = acc ? (state_t)y[j] : x[j];
+      j2 = acc ? (state_t)jump : (state_t)0;
+      lp = lp_mh;
+    } else if (!swap_due) {
 #pragma unroll
       for (int j = 0; j < W; ++j) {
         if (q_valid<MIN_OWN>(l, j)) {

@@ -33,14 +33,20 @@ constexpr float kNegInf = -__builtin_huge_valf();
 // log of the 3-term sum is deferred: sum_d log2(s_d) = log2(prod_d s_d) with
 // s_d in [1,3], two v_log_f32 per evaluation instead of one per dimension.  All
 // sums over dimensions run in the canonical four-range order (philox.h).
-// One dimension of the rough carpet from its three centred coordinates: mx = the largest exponent (log2 domain),
-// s = 1 + 2^(md - mx) (+ 2^(mn - mx)): the sum of the three terms relative to the largest.  Shared by both kernels.
+// One dimension of the rough carpet from its three centred coordinates, each already scaled by kRcScale = sqrt(log2(e) / 2)
+// so that the exponent of component k in the log2 domain is w_k - d_k^2: ONE fma per component (the caller forms d_k as one
+// fma too: kRcScale x - kRcScale m_k; round 2 spent a subtraction, a square and an fma per component - three VALU
+// instructions per dimension more, 8 % of the BASELINE step).  mx = the largest exponent, s = 1 + 2^(md - mx)
+// (+ 2^(mn - mx)): the sum of the three terms relative to the largest.  Shared by both kernels.
+// Accuracy: the square is still taken of the CENTRED coordinate (nothing is expanded); the only new rounding is that of the
+// product kRcScale m_k, 6e-8 relative - for the component the point is close to it changes the exponent by
+// 2 d_k 7.6e-7 ~ 0, for a far component by < 4e-5 in an exponent that no longer matters there.
+constexpr float kRcScale = 0.84932180028801904f;  // sqrt(0.5 * log2(e))
 template <bool STRICT, bool TWO>
-__device__ __forceinline__ void rc_dim_term(float d0, float d1, float d2, float nh, float w0, float w1, float w2,
-                                            float &mx, float &s) {
-  const float a0 = fmaf(d0 * d0, nh, w0);
-  const float a1 = fmaf(d1 * d1, nh, w1);
-  const float a2 = fmaf(d2 * d2, nh, w2);
+__device__ __forceinline__ void rc_dim_term(float d0, float d1, float d2, float w0, float w1, float w2, float &mx, float &s) {
+  const float a0 = fmaf(-d0, d0, w0);
+  const float a1 = fmaf(-d1, d1, w1);
+  const float a2 = fmaf(-d2, d2, w2);
   mx = __builtin_fmaxf(__builtin_fmaxf(a0, a1), a2);
   const float md = __builtin_amdgcn_fmed3f(a0, a1, a2);
   const float sh = STRICT ? __builtin_fmaxf(mx, -3.0e38f) : mx;
@@ -71,24 +77,20 @@ struct RoughCarpetT {
   // bit-identical output.  True for the +-15 modes of the benchmark target, false e.g. for modes +-4.
   template <bool SCALED, bool STRICT, bool TWO>
   __device__ __forceinline__ static float logp_impl(const float (&y)[DP], int D, const TParams &tp) {
-    const float m0 = tp.p[0], m1 = tp.p[1], m2 = tp.p[2];
+    // the modes on the scaled axis, negated (the addend of the fma that centres a coordinate)
+    const float m0 = -(tp.p[0] * kRcScale), m1 = -(tp.p[1] * kRcScale), m2 = -(tp.p[2] * kRcScale);
     [[maybe_unused]] const const_float_ptr uv0 = SCALED ? uniform_vec(tp.vec0) : nullptr;
     // log2-domain log-weights
     const float w0 = tp.p[3] * kLog2e, w1 = tp.p[4] * kLog2e, w2 = tp.p[5] * kLog2e;
-    const float nh = -0.5f * kLog2e;
     constexpr int W = canon_width(DP);
     float sm[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pr[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // canonical four-range partials (philox.h)
     PTRWM_DIM_LOOP(d, DP, D, {
       float d0, d1, d2;
-      if constexpr (SCALED) {
-        // s x - m_k as ONE explicit fma each (what the optimiser chose when left alone, now the same in every kernel)
-        const float sc = uv0[d];
-        d0 = fmaf(y[d], sc, -m0), d1 = fmaf(y[d], sc, -m1), d2 = fmaf(y[d], sc, -m2);
-      } else {
-        d0 = y[d] - m0, d1 = y[d] - m1, d2 = y[d] - m2;
-      }
+      // kRcScale (s x - m_k) as ONE explicit fma per component, the same in every kernel
+      const float sc = SCALED ? uv0[d] * kRcScale : kRcScale;
+      d0 = fmaf(y[d], sc, m0), d1 = fmaf(y[d], sc, m1), d2 = fmaf(y[d], sc, m2);
       float mx, s;
-      rc_dim_term<STRICT, TWO>(d0, d1, d2, nh, w0, w1, w2, mx, s);
+      rc_dim_term<STRICT, TWO>(d0, d1, d2, w0, w1, w2, mx, s);
 #ifdef PTRWM_RC_PROD_FIRST
       pr[d / W] = mul_rn(pr[d / W], s);
       sm[d / W] = add_rn(sm[d / W], mx);

@@ -512,8 +512,9 @@ class RunPlan:
     def _split_buffers(self):
         if getattr(self, "_split", None) is None:
             Cn, T, D = self.shape
+            # proposals, and the two planes of the accept scratch (uniforms; the proposal's own squared jump or -1)
             self._split = (torch.empty(Cn, T, D, device=self.device, dtype=torch.float32),
-                           torch.empty(Cn, T, device=self.device, dtype=torch.float32))
+                           torch.empty(2, Cn, T, device=self.device, dtype=torch.float32))
         return self._split
 
     def split_propose(self, step: int, ext_prop: Optional[torch.Tensor] = None,

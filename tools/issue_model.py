@@ -201,8 +201,9 @@ def main():
     smem = sum(c for o, c in ops.items() if o.startswith(("s_load", "s_buffer")))
     print(f"kernel {name}\nstep loop header {header}; path of a step without a swap event: {' '.join(path)} (penalty {pen})")
     print(f"instructions on the path: {sum(ops.values())} = {valu} VALU + {salu} SALU + {smem} scalar loads + "
-          f"{sum(c for o, c in ops.items() if o.startswith('ds_'))} LDS + {ops.get('s_nop', 0)} s_nop + {ops.get('s_waitcnt', 0)} s_waitcnt")
-    ok = True
+          f"{sum(c for o, c in ops.items() if o.startswith('ds_'))} LDS + {ops.get('s_nop', 0)} s_nop + {ops.get('s_waitcnt', 0)} s_waitcnt + "
+          f"{sum(c for o, c in ops.items() if o.startswith('scratch_'))} scratch")
+    ok = sum(c for o, c in ops.items() if o.startswith("scratch_")) == 0  # no spill traffic on the step path
     for what, got, want in (("VALU", valu, a.valu_per_wave_step), ("SALU", salu, a.salu_per_wave_step)):
         if want:
             rel = got / want - 1
