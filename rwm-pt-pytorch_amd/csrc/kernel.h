@@ -369,6 +369,14 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
   const float tscale = a.temp_scale[t];
   // one vote per launch: may the group's sequential sweeps take the threshold form?  (swap_decide)
   const bool swap_plain = group_all(swap_threshold_ok(T, t, a.beta, beta_t, lp));
+  // may the proposal's own squared increment stand for |y - x|^2 for this replica?  (proposals.h kJumpTrust)
+  bool jump_trusted = false;
+  if constexpr (Proposal::kKnowsJump) {
+    float xmax = 0.0f;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) xmax = __builtin_fmaxf(xmax, __builtin_fabsf(x[d]));  // (slots >= dim hold 0)
+    jump_trusted = xmax <= kJumpTrust * Proposal::increment_scale(tscale, a.pp);  // (NaN: false)
+  }
 
   const unsigned long long gchain = (unsigned long long)(a.chain_offset + chain);
   RngCtx rc;
@@ -438,12 +446,23 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
 
     float j2;
     if (!swap_due && jump_kind != kJumpNone) {
-      // the proposal knows the length of its own increment: the move itself is one select per dimension
+      // the proposal knows the length of its own increment: the move itself is one select per dimension.  Replicas whose
+      // state is too large for that to equal |y - x|^2 (jump_trusted, decided at the start of the launch: none, normally -
+      // the branch is skipped) take it from the states
+      float from_states = 0.0f;
+      if (!jump_trusted) {
+        float j2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        PTRWM_DIM_LOOP(d, DP, D, {
+          const float dl = sub_rn(y[d], x[d]);
+          j2p[d / W] = fmaf(dl, dl, j2p[d / W]);
+        })
+        from_states = tree4_add(j2p);
+      }
       PTRWM_DIM_LOOP(d, DP, D, {
         x[d] = acc ? y[d] : x[d];
         if ((d & PTRWM_J2_FENCE_MASK) == PTRWM_J2_FENCE_MASK) sched_fence_soft();
       })
-      j2 = acc ? jump : 0.0f;
+      j2 = acc ? (jump_trusted ? jump : from_states) : 0.0f;
       lp = lp_mh;
     } else if (!swap_due) {
       float j2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // squared jump in the canonical four-range order (philox.h)
@@ -685,7 +704,11 @@ __global__ void __launch_bounds__(kBlockThreads, standalone_min_waves(DP)) ptrwm
   accept_u[i] = u;
   // second plane of the scratch array: the proposal's own squared jump, exactly as the fused kernel counts it, or -1 when
   // it is to be taken from the states (external randoms, Laplace): split_accept_kernel then reproduces ptrwm_run's sums
-  accept_u[n_chains * T + i] = jump_kind == kJumpTotal ? jump : -1.0f;
+  float xmax = 0.0f;
+#pragma unroll
+  for (int d = 0; d < DP; ++d) xmax = __builtin_fmaxf(xmax, __builtin_fabsf(x[d]));
+  const bool trusted = Proposal::kKnowsJump && xmax <= kJumpTrust * Proposal::increment_scale(temp_scale[t], pp);  // (proposals.h)
+  accept_u[n_chains * T + i] = (jump_kind == kJumpTotal && trusted) ? jump : -1.0f;
 }
 
 }  // namespace ptrwm

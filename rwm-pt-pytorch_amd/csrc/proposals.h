@@ -29,6 +29,13 @@ struct RngCtx {
 // returns - one live register across the density evaluation, not four).  kJumpPartial (lane-split form only): `jump` is
 // this lane's range, to be combined across the quad by the caller.
 enum { kJumpNone = 0, kJumpPartial = 1, kJumpTotal = 2 };
+// The reference's statistic is |x_t - x_{t-1}|^2 of the STORED states (rwm_gpu_optimized.py:513-534,
+// pt_rwm_gpu_optimized.py:772-789).  The increment's own length stands in for it only where the float sum x + inc keeps the
+// increment: a replica whose largest coordinate exceeds kJumpTrust typical increments per dimension (half an ulp of x is
+// then more than 2^-16 of the increment: the two definitions part beyond ~3e-5 relative) takes its jump from the states,
+// as before.  Decided per replica, from its own state and scale only (so neither the kernel form nor the sharding can
+// change it), when a launch loads the state: `jump_trusted()` of the kernels.
+constexpr float kJumpTrust = 256.0f;
 
 struct PParams {
   const float *__restrict__ dim_scale;  // [D] Laplace, wave-uniform
@@ -162,6 +169,9 @@ __device__ __forceinline__ float philox_normal_step(float (&y)[DP], const float 
 template <int DP>
 struct NormalProposal {
   static constexpr int kKind = PTRWM_PROPOSAL_NORMAL;
+  static constexpr bool kKnowsJump = true;
+  // the size of a typical per-dimension increment (for jump_trusted)
+  __device__ __forceinline__ static float increment_scale(float tscale, const PParams &) { return tscale; }
   __device__ __forceinline__ static float propose(float (&y)[DP], const float (&x)[DP], int D,
                                                   float tscale, const PParams &, const RngCtx &rc,
                                                   const float *ext_raw, float ext_u, float &jump, int &jump_kind) {
@@ -184,6 +194,8 @@ struct NormalProposal {
 template <int DP>
 struct LaplaceProposal {
   static constexpr int kKind = PTRWM_PROPOSAL_LAPLACE;
+  static constexpr bool kKnowsJump = false;
+  __device__ __forceinline__ static float increment_scale(float tscale, const PParams &) { return tscale; }
   __device__ __forceinline__ static float transform(float u01v, float scale) {
     const float u = u01v - 0.5f;
     const float au = __builtin_fabsf(u);
@@ -244,6 +256,8 @@ struct LaplaceProposal {
 template <int DP>
 struct UniformRadiusProposal {
   static constexpr int kKind = PTRWM_PROPOSAL_UNIFORM_RADIUS;
+  static constexpr bool kKnowsJump = true;
+  __device__ __forceinline__ static float increment_scale(float tscale, const PParams &pp) { return tscale * hw_sqrt(pp.inv_dim); }
   __device__ __forceinline__ static float propose(float (&y)[DP], const float (&x)[DP], int D,
                                                   float tscale, const PParams &pp, const RngCtx &rc,
                                                   const float *ext_raw, float ext_u, float &jump, int &jump_kind) {

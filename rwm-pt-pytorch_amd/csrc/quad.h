@@ -98,6 +98,8 @@ __device__ __forceinline__ bool q_valid(const QLane &l, int j) {
 template <int W, int MIN_OWN>
 struct QNormal {
   static constexpr int kKind = PTRWM_PROPOSAL_NORMAL;
+  static constexpr bool kKnowsJump = true;
+  __device__ __forceinline__ static float increment_scale(float tscale, const PParams &) { return tscale; }
   // jump / jump_kind: proposals.h (this lane's range of the squared jump: kJumpPartial sums are combined by the caller)
   __device__ __forceinline__ static float propose(float (&y)[W], const float (&x)[W], const QLane &l, int D, float tscale,
                                                   const PParams &, const RngCtx &rc, const float *ext_rep, float ext_u,
@@ -155,6 +157,8 @@ struct QNormal {
 template <int W, int MIN_OWN>
 struct QLaplace {
   static constexpr int kKind = PTRWM_PROPOSAL_LAPLACE;
+  static constexpr bool kKnowsJump = false;
+  __device__ __forceinline__ static float increment_scale(float tscale, const PParams &) { return tscale; }
   __device__ __forceinline__ static float propose(float (&y)[W], const float (&x)[W], const QLane &l, int D, float tscale,
                                                   const PParams &pp, const RngCtx &rc, const float *ext_rep, float ext_u,
                                                   float &, int &jump_kind) {
@@ -197,6 +201,8 @@ struct QLaplace {
 template <int W, int MIN_OWN>
 struct QUniformRadius {
   static constexpr int kKind = PTRWM_PROPOSAL_UNIFORM_RADIUS;
+  static constexpr bool kKnowsJump = true;
+  __device__ __forceinline__ static float increment_scale(float tscale, const PParams &pp) { return tscale * hw_sqrt(pp.inv_dim); }
   __device__ __forceinline__ static float propose(float (&y)[W], const float (&x)[W], const QLane &l, int D, float tscale,
                                                   const PParams &pp, const RngCtx &rc, const float *ext_rep, float ext_u,
                                                   float &jump, int &jump_kind) {
@@ -695,6 +701,17 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
   float lp = a.logp[rep];
   const float beta_t = a.beta[t];
   const float tscale = a.temp_scale[t];
+  // may the proposal's own squared increment stand for |y - x|^2 for this replica?  (proposals.h kJumpTrust: the replica's
+  // largest coordinate, over all four lanes, against the increment scale - the same verdict as the thread form's)
+  bool jump_trusted = false;
+  if constexpr (Proposal::kKnowsJump && !F64) {
+    float xmax = 0.0f;
+#pragma unroll
+    for (int j = 0; j < W; ++j) xmax = __builtin_fmaxf(xmax, __builtin_fabsf((float)x[j]));  // (slots not owned hold 0)
+    xmax = __builtin_fmaxf(xmax, dpp_f<kDppSwapPair>(xmax));
+    xmax = __builtin_fmaxf(xmax, dpp_f<kDppSwapHalf>(xmax));
+    jump_trusted = xmax <= kJumpTrust * Proposal::increment_scale(tscale, a.pp);
+  }
   // one vote per launch: may the group's sequential sweeps take the threshold form?  (kernel.h swap_decide)
   const bool swap_plain_here = swap_threshold_ok(T, t, a.beta, beta_t, lp);
   const bool swap_plain = wide ? (__syncthreads_and(swap_plain_here ? 1 : 0) != 0) : (__builtin_amdgcn_ballot_w64(!swap_plain_here) == 0ull);
@@ -784,11 +801,23 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
     state_t j2l = 0;  // this lane's range of the squared jump
     state_t j2;
     if (!swap_due && jump_kind != kJumpNone) {
-      // (float states only) the proposal knows the length of its own increment: the move is one select per dimension
+      // (float states only) the proposal knows the length of its own increment: the move is one select per dimension;
+      // replicas that may not trust it (kernel.h) take the jump from the states
+      float from_states = 0.0f;
+      if (!jump_trusted) {
+        float p = 0.0f;
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+          if (q_valid<MIN_OWN>(l, j)) {
+            const float dl = sub_rn(y[j], (float)x[j]);
+            p = fmaf(dl, dl, p);
+          }
+        from_states = quad_tree_add(p);
+      }
 #pragma unroll
       for (int j = 0; j < W; ++j)
         if (q_valid<MIN_OWN>(l, j)) x[j] = acc ? (state_t)y[j] : x[j];
-      j2 = acc ? (state_t)jump : (state_t)0;
+      j2 = acc ? (state_t)(jump_trusted ? jump : from_states) : (state_t)0;
       lp = lp_mh;
     } else if (!swap_due) {
 #pragma unroll

@@ -820,12 +820,17 @@ def test_philox_stream_quality_on_the_run_layout(device):
     zeros = torch.zeros(Cn, T, D, device=device)
     plan = E.RunPlan(None, prop.engine(device), state=zeros, logp=torch.zeros(Cn, T, device=device), beta=dev_t(beta, device),
                      seed=20240607, chain_offset=123456789)
-    z, u = [], []
+    z, u, j = [], [], []
     for s in range(steps):
         props = plan.split_propose(s)  # state is zero: the proposals are the increments
         z.append((props / dev_t(prop.temp_scale, device)[None, :, None]).cpu().numpy().astype(np.float64))
-        u.append(plan._split_buffers()[1].cpu().numpy().astype(np.float64))
-    z, u = np.stack(z), np.stack(u)  # [steps, C, T, D], [steps, C, T]
+        # (the accept scratch has two planes: the uniforms, and the squared length of the increment as the proposal itself
+        # counts it - the sum of its Box-Muller pairs' squared radii, never |y - x|^2 recomputed)
+        acc_u, jump = plan._split_buffers()[1]
+        u.append(acc_u.cpu().numpy().astype(np.float64))
+        j.append((jump / dev_t(prop.temp_scale, device)[None, :] ** 2).cpu().numpy().astype(np.float64))
+    z, u, j = np.stack(z), np.stack(u), np.stack(j)  # [steps, C, T, D], [steps, C, T], [steps, C, T]
+    np.testing.assert_allclose(j, (z ** 2).sum(-1), rtol=2e-5)  # ... and it IS the squared length of the increment
     n = z.size
     assert stats.kstest(z.ravel(), "norm").pvalue > 1e-4
     assert abs(z.mean()) < 5 / np.sqrt(n) and abs(z.var() - 1.0) < 5 * np.sqrt(2.0 / n)
@@ -931,6 +936,44 @@ def test_float64_states_keep_increments_a_float_state_loses(device):
     moved = np.abs(g64["state"] - st)
     assert moved.min() > 0 and 1e-4 < np.sqrt((moved**2).mean()) < 1e-2  # a random walk of 200 steps of 1e-4
     assert g64["sq_jump"].sum() / (Cn * N) == pytest.approx(dim * 1e-8, rel=0.1)
+
+
+@pytest.mark.parametrize("prop_name", ["Normal", "UniformRadius"])
+def test_squared_jump_is_that_of_the_stored_states(device, prop_name):
+    """rwm_gpu_optimized.py:513-534 / pt_rwm_gpu_optimized.py:772-789 define the statistic on the STORED states.  The
+    production kernels take the squared length from the proposal itself where the two agree (proposals.h kJumpTrust) and
+    from the states where they do not.  A batch mixing both kinds of replica - half near the origin, half 3e4 away where a
+    float state swallows most of each increment - must report, per replica, the squared jumps of its own stored trace, and
+    the same bits in both kernel forms."""
+    dim, Cn, N = 30, 64, 60
+    far = np.zeros((Cn, 1, 1), np.float32)
+    far[Cn // 2:] = 3.0e4
+    mean = np.zeros(dim, np.float32)
+    spec = H.TargetSpec(O.TARGET_DIAG_GAUSSIAN, dim, (np.float32(-0.5 * dim * np.log(2 * np.pi)),), (0,), mean, np.full(dim, 1e-10, np.float32))
+    # (a nearly flat target: every move accepted wherever the replica sits)
+    prop = H.proposal_spec(prop_name, dim, [1.0], base_variance_scalar=1e-4, base_radius=0.05, single=True)
+    rng = np.random.default_rng(3)
+    st = (far + 0.1 * rng.normal(size=(Cn, 1, dim)).astype(np.float32)).astype(np.float32)  # near: |x| < 0.5, trusted
+    lp = O.logdensity(spec.oracle(), st.reshape(-1, dim)).reshape(Cn, 1)
+    kw = dict(state=st, logp=lp, beta=np.float32([1.0]), step0=0, n_steps=N, burn_in=0, swap_every=1, seed=5, trace_temps=1)
+    runs = {}
+    for form in (E.FORM_THREAD, E.FORM_QUAD):
+        with E.kernel_form(form):
+            runs[form] = gpu_run(spec, prop, device, **kw)
+    g = runs[E.FORM_THREAD]
+    for k in ("state", "logp", "n_accept", "sq_jump", "trace"):
+        assert np.array_equal(g[k], runs[E.FORM_QUAD][k]), k
+    assert g["n_accept"].min() > 0.8 * N
+    path = np.concatenate([st[None], g["trace"]], axis=0).astype(np.float64)  # [N+1, Cn, 1, dim]
+    want = (np.diff(path, axis=0) ** 2).sum(axis=(0, 3))
+    near_err = np.abs(g["sq_jump"][: Cn // 2] / want[: Cn // 2] - 1).max()
+    far_err = np.abs(g["sq_jump"][Cn // 2:] / want[Cn // 2:] - 1).max()
+    assert near_err < 1e-5, near_err   # the proposal's own length: the float sum x + inc keeps the increment here
+    assert far_err < 1e-6, far_err     # |y - x|^2 of the states themselves (fp32 accumulation order only)
+    # ... and the two definitions really differ out there (an ulp of 3e4 is 2e-3, the increments are ~1e-2)
+    intended = dim * 1e-4 * N if prop_name == "Normal" else None
+    if intended is not None:
+        assert np.abs(want[Cn // 2:] / intended - 1).mean() > 5e-3
 
 
 def test_float64_argument_validation(device):
