@@ -451,6 +451,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       // the branch is skipped) take it from the states
       float from_states = 0.0f;
       if (!jump_trusted) {
+        PTRWM_COLD_PATH();
         float j2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         PTRWM_DIM_LOOP(d, DP, D, {
           const float dl = sub_rn(y[d], x[d]);

@@ -86,6 +86,10 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 #define PTRWM_VALUE_BARRIER(...) asm volatile("" : __VA_ARGS__)
 #endif
 
+// A comment in the emitted assembly marking a block that an ordinary step does not enter (tools/issue_model.py leaves such
+// blocks off the step path it prices); no instruction.
+#define PTRWM_COLD_PATH() asm volatile("; ptrwm-cold-path")
+
 // Parameter vectors (means, per-dimension scales) are read-only for the whole launch and indexed wave-uniformly.
 // Read through the constant address space they become scalar loads (s_load_dwordx*, SGPR operands) instead of
 // 64-lane vector loads of a single address.  (No kernel writes them, so the scalar cache cannot go stale.)

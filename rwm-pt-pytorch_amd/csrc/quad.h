@@ -805,6 +805,7 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
       // replicas that may not trust it (kernel.h) take the jump from the states
       float from_states = 0.0f;
       if (!jump_trusted) {
+        PTRWM_COLD_PATH();
         float p = 0.0f;
 #pragma unroll
         for (int j = 0; j < W; ++j)

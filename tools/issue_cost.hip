@@ -14,7 +14,7 @@
 enum Op {
   ADD_F32, MUL_F32, FMA_F32, FMAMK_F32, MAX3_F32, MED3_F32, CNDMASK, XOR_B32, LSHRREV, CVT_F32_U32, AND_OR, ADD_U32, BITOP3,
   MAD_U64_U32, MUL_LO_U32, EXP_F32, LOG_F32, SQRT_F32, SIN_F32, COS_F32, RCP_F32, CVT_F64_F32, ADD_F64, FMA_F64, CMP_F32,
-  READLANE, WRITELANE, MOV_DPP, DS_READ_B32, DS_WRITE_B32, DS_READ_B128,
+  READLANE, WRITELANE, MOV_DPP, DS_READ_B32, DS_WRITE_B32, DS_READ_B128, PK_FMA_F32, PK_MUL_F32, PK_ADD_F32,
   // mixes (per GROUP of four instructions, not per instruction): do instruction classes overlap on the SIMD?
   MIX_EXP_FMA3, MIX_MAD_BITOP_FMA2, MIX_EXP_MAD_BITOP_FMA, N_OPS
 };
@@ -23,6 +23,7 @@ static const char *kNames[N_OPS] = {
   "v_lshrrev_b32", "v_cvt_f32_u32", "v_and_or_b32", "v_add_u32", "v_bitop3_b32", "v_mad_u64_u32", "v_mul_lo_u32",
   "v_exp_f32", "v_log_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32", "v_rcp_f32", "v_cvt_f64_f32", "v_add_f64", "v_fma_f64",
   "v_cmp_lt_f32", "v_readlane_b32", "v_writelane_b32", "v_mov_b32_dpp", "ds_read_b32", "ds_write_b32", "ds_read_b128",
+  "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32",  // (two fp32 results per lane each)
   "mix:v_exp_f32+3*v_fma_f32", "mix:v_mad_u64_u32+v_bitop3_b32+2*v_fma_f32", "mix:v_exp_f32+v_mad_u64_u32+v_bitop3_b32+v_fma_f32"};
 
 template <int OP>
@@ -47,6 +48,11 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed) {
   const uint64_t lane_mask = 0x5555555555555555ull ^ seed;
   typedef float vec4 __attribute__((ext_vector_type(4)));
   vec4 q4 = {0, 0, 0, 0};
+  typedef float vec2 __attribute__((ext_vector_type(2)));
+  vec2 g[8];
+  const vec2 g1 = {c1, c1}, g2 = {c2, c2};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) g[i] = vec2{f[i], f[i] + 1.0f};
   for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
@@ -86,6 +92,9 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed) {
         if (OP == DS_READ_B32) asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(f[i]) : "v"((uint32_t)(threadIdx.x * 4)));
         if (OP == DS_WRITE_B32) asm volatile("ds_write_b32 %0, %1" : : "v"((uint32_t)(threadIdx.x * 4)), "v"(f[i]) : "memory");
         if (OP == DS_READ_B128) asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(q4) : "v"((uint32_t)(threadIdx.x * 16)));
+        if (OP == PK_FMA_F32) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(g[i]) : "v"(g1), "v"(g2));
+        if (OP == PK_MUL_F32) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(g[i]) : "v"(g1));
+        if (OP == PK_ADD_F32) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(g[i]) : "v"(g2));
         // mixes: one GROUP of four independent instructions per slot (a quarter as many groups: i < 2 only)
         if (OP == MIX_EXP_FMA3 && i < 2) {
           asm volatile("v_exp_f32 %0, %0" : "+v"(f[i]));
@@ -114,6 +123,8 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += a[i] + (uint32_t)f[i] + (uint32_t)d[i] + (uint32_t)p[i];
   s += (uint32_t)q4.x;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += (uint32_t)g[i].x + (uint32_t)g[i].y;
   if (s == 0x12345678u) out[threadIdx.x] = s;
 }
 

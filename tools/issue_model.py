@@ -103,6 +103,7 @@ def features(b):
         "lds": sum(o.startswith("ds_") for o in ops), "barrier": sum(o == "s_barrier" for o in ops),
         "sload": sum(o.startswith("s_load") for o in ops), "inner": int("Depth=2" in b["notes"] or "Depth 2" in b["notes"] and "Child" not in b["notes"]),
         "global": sum(o.startswith(("global_", "flat_", "buffer_", "scratch_")) for o in ops),
+        "cold": int("ptrwm-cold-path" in b["notes"]),  # PTRWM_COLD_PATH() of philox.h
     }
 
 
@@ -118,7 +119,7 @@ def step_path(blocks, order):
 
     def cost(t):
         f = features(blocks[t])
-        return 10 * f["lds"] + 1000 * f["barrier"] + 3 * f["sload"] + 1000 * f["inner"] + 5 * f["global"]
+        return 10 * f["lds"] + 1000 * f["barrier"] + 3 * f["sload"] + 1000 * f["inner"] + 5 * f["global"] + 100 * f["cold"]
 
     def best_from(b):
         """(penalty, -valu, next block) of the best continuation from the END of block b to the header."""
@@ -128,9 +129,10 @@ def step_path(blocks, order):
             return (INF[0], 0, None)
         visiting.add(b)
         out = (INF[0], 0, None)
+        falls_cold = any(k == "fall" and features(blocks[t])["cold"] for k, t in blocks[b]["succ"])
         for kind, t in blocks[b]["succ"]:
-            if kind.startswith("s_cbranch_exec"):
-                continue  # a skip over a block for waves without live lanes: not taken
+            if kind.startswith("s_cbranch_exec") and not falls_cold:
+                continue  # a skip over a block for waves without live lanes: not taken (but taken over a cold block)
             if t == header:
                 cand = (0, 0, header)
             elif t in in_loop:
