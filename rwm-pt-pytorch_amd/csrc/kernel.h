@@ -257,11 +257,18 @@ __device__ __forceinline__ void stage_copy(float *__restrict__ lds, float *__res
   }
 }
 
-// the value, re-materialised in a VGPR at this point: stops the compiler from sharing (and keeping live) anything
-// derived from it with code before this point
-__device__ __forceinline__ int opaque_vgpr(int v) {
-  PTRWM_VALUE_BARRIER("+v"(v));
-  return v;
+// The thread's index in its (one-dimensional) workgroup, re-derived from the hardware where it is needed - the lane from
+// v_mbcnt, the wave's index in the workgroup from an SGPR set once at kernel entry (lanes fill the waves of a 1-D workgroup
+// in order) - so that neither threadIdx.x nor anything computed from it has to live in a VGPR, i.e. in scratch, across the
+// step loop: at the 128-VGPR cap the allocator spilled it and four words derived from it (28 B of scratch per thread,
+// 13 % of a launch's HBM traffic at 2 000 steps per launch).  Used by the swap path and the epilogue alike: with the
+// epilogue alone re-deriving it the headline kernel ran 2 % slower (95.1 against 93.1 ms per 2 000-step launch, same box,
+// profiles/r03_scratch_ab.txt) - register allocation at the cap is that sensitive; candidates are A/B-timed.
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ int thread_index_now(int wave) {
+  unsigned all = ~0u;
+  PTRWM_VALUE_BARRIER("+s"(all));  // (v_mbcnt is pure: without this it is computed once, before the loop, and kept)
+  return wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(all, __builtin_amdgcn_mbcnt_lo(all, 0u));
 }
 
 template <bool EXACT>
@@ -317,6 +324,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
   // independent groups), or ceil(T / 64) wavefronts = the whole workgroup holding one ladder ("wide", cpw = 1).
   // Thread tid of its group is (cw, t) with tid = cw * T + t either way.
   const bool wide = T > 64;  // grid-uniform
+  const int wave = wave_in_block();  // (an SGPR for the whole launch: thread_index_now)
   const int tid = wide ? (int)threadIdx.x : (int)(threadIdx.x & 63);
   const long long chain0 = (wide ? (long long)blockIdx.x : (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * cpw;
   if (chain0 >= a.n_chains) return;  // narrow only (wave-uniform; narrow waves never meet at a workgroup barrier)
@@ -494,7 +502,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       // ---- temperature swaps on the post-MH log-densities (pt_rwm_gpu_optimized.py:594-633) ----
       // The exchange indices are rebuilt here from an opaque copy of threadIdx.x, so that none of them occupies a
       // register (or a scratch slot) across the MH part of the step.
-      const int tid_s = opaque_vgpr((int)threadIdx.x);
+      const int tid_s = thread_index_now(wave);
       const int slot = wide ? tid_s : (tid_s & 63);  // this thread's slot in s_l / s_u and its row in s_stage
       const int group_threads = wide ? ((T + 63) & ~63) : 64;
       float *const rows = s_dyn + (wide ? 0 : (tid_s >> 6) * (64 * (DP + kLdsExtraPerThread)));
@@ -575,10 +583,11 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     // everything is recomputed from opaque copies so that nothing of the prologue stays live across the step loop
     const int T2 = fresh_dim<false>(T), D2 = EXACT ? DP : fresh_dim<false>(D0), cpw2 = fresh_dim<false>(cpw);
     const bool wide2 = T2 > 64;
-    const int tid2 = wide2 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
-    float *const rows2 = s_dyn + (wide2 ? 0 : (int)(threadIdx.x >> 6) * (64 * (DP + kLdsExtraPerThread)));
+    const int tx2 = thread_index_now(wave);
+    const int tid2 = wide2 ? tx2 : (tx2 & 63);
+    float *const rows2 = s_dyn + (wide2 ? 0 : wave * (64 * (DP + kLdsExtraPerThread)));
     const long long bid = (long long)fresh_dim<false>((int)blockIdx.x);  // re-read here, not carried in a VGPR
-    const long long c0 = (wide2 ? bid : bid * kWavesPerBlock + (threadIdx.x >> 6)) * cpw2;
+    const long long c0 = (wide2 ? bid : bid * kWavesPerBlock + wave) * cpw2;
     const long long n_chains2 = ae->n_chains;
     const long long live_chains = (n_chains2 - c0 < cpw2) ? (n_chains2 - c0) : cpw2;
     const int stage_total = (int)live_chains * T2 * D2;
@@ -597,7 +606,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     stage_copy<false>(rows2, gs, stage_total, tid2, nthr);
   }
   if (live) {
-    const int tid_o = opaque_vgpr((int)threadIdx.x);
+    const int tid_o = thread_index_now(wave);
     const int T_o = fresh_dim<false>(T);
     const long long rep = c0_out * T_o + (T_o > 64 ? tid_o : (tid_o & 63));  // live: replica index in group == tid
     const int gt_o = T_o > 64 ? ((T_o + 63) & ~63) : 64;

@@ -75,7 +75,7 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 
 // Value barriers.  PTRWM_VALUE_BARRIER("+s" / "+v", x) is an EMPTY inline asm that names x as read and written: no
 // instruction, but the optimiser must treat x as a new value from here on - it can neither hoist what is computed from it
-// out of the step loop nor share it with the code before.  Every use in this library is of that kind (kernel.h opaque_vgpr
+// out of the step loop nor share it with the code before.  Every use in this library is of that kind (kernel.h thread_index_now
 // / fresh_dim / late_args, uniform_vec below, quad.h q_fresh, targets.h HybridRosenbrock) and exists to keep loop-invariant
 // values out of registers - i.e. out of spill lanes - across the ~1 500-instruction step loop.  Building with
 // -DPTRWM_NO_VALUE_BARRIERS removes all of them (analysis only: tools/barrier_diff.py compiles both ways and records what

@@ -264,9 +264,11 @@ def test_auto_form_rule_is_the_fitted_model(engine):
             for w in (0.1, 0.3, 0.6, 0.9, 1.0, 1.1, 1.4, 1.6, 1.9, 2.0, 2.2, 2.75, 3.5, 4.0, 5.0):
                 waves = max(1, int(round(w * simds)))
                 C = waves * cpw  # whole waves: w is then exactly waves / simds
-                want = F.quad_faster(model, dim, T, waves / simds)
+                th, qu = F.rates(model, dim, T, waves / simds)
                 got = engine.auto_form(engine.TARGET_ROUGH_CARPET, engine.PROPOSAL_NORMAL, dim, T, C)
-                assert got == (engine.FORM_QUAD if want else engine.FORM_THREAD), (dim, T, w, C)
+                if abs(th - qu) < 2e-3 * max(th, qu):
+                    continue  # a tie within the table's four decimals: either form is right
+                assert got == (engine.FORM_QUAD if qu > th else engine.FORM_THREAD), (dim, T, w, C)
                 n += 1
     assert n > 2000
     assert engine.auto_form(0, 0, 10, 8, 1) == engine.FORM_THREAD      # dim < 16: never lane-split

@@ -69,9 +69,15 @@ def params(model, dim, T):
 
 
 def quad_faster(model, dim, T, w):
+    thread, quad = rates(model, dim, T, w)
+    return quad > thread
+
+
+def rates(model, dim, T, w):
+    """(thread form, lane-split form) modelled rates relative to the thread form at 4 waves per SIMD."""
     ws = model[2]
     if w > ws[-1]:
-        return False
+        return 1.0, 0.0
     a, q = params(model, dim, T)
     k = max(1, math.ceil(w - 1e-9))
     thread = a[k - 1] * w / k
@@ -87,7 +93,7 @@ def quad_faster(model, dim, T, w):
         i = min(max(j for j in range(len(ws)) if ws[j] <= wu + 1e-9), len(ws) - 2)
         b = q[i] + (q[i + 1] - q[i]) * (min(wu, ws[-1]) - ws[i]) / (ws[i + 1] - ws[i])
     quad = b * (4 * w / kq)
-    return quad > thread
+    return thread, quad
 
 
 def regret(model, tab, tag):
