@@ -172,7 +172,11 @@ typedef struct ptrwm_run_args {
   const float *beta; /* [n_temps] inverse temperatures, beta[0] is the cold chain */
   /* statistics, device, accumulated (+=); any may be NULL */
   int64_t *n_accept;    /* [n_chains, n_temps] MH acceptances at steps with step_counter > burn_in */
-  double *sq_jump;      /* [n_chains, n_temps] sum of |x_t - x_{t-1}|^2 over those steps (swap moves included) */
+  double *sq_jump;      /* [n_chains, n_temps] sum of |x_t - x_{t-1}|^2 over those steps (swap moves included).  For an
+                         * accepted Metropolis move of the Normal / UniformRadius proposals in Philox mode this is the
+                         * squared length of the increment itself, which equals that of the float sum x + inc to ~3e-5
+                         * relative or better wherever it is used: a replica whose largest |coordinate| exceeds 256
+                         * typical increments when a launch loads it takes the jump from the states instead. */
   int64_t *swap_accept; /* [n_chains, n_temps] accepted swaps of pair (t, t+1); column n_temps-1 unused */
   int64_t *last_swap_ordinal; /* [n_chains, n_temps] max 1-based attempt ordinal at which pair t accepted */
   /* schedule: this call performs steps step0 .. step0+n_steps-1 (0-based); step i has
