@@ -397,7 +397,20 @@ def check_parity(run_a, run_b, spec, prop, *, state, logp, beta, n_steps, burn_i
                     f"no swap event has those pairs' uniforms inside the fp32 band of their thresholds (in band: {sorted(in_band)})"
                 assert np.abs(got["swap_accept"][c] - want["swap_accept"][c]).max() <= 2
                 flips.append((step0, c, "swap-invisible", 0.0))
-            np.testing.assert_allclose(got["sq_jump"][c], want["sq_jump"][c], rtol=1e-4, atol=1e-9)
+            if exact_states:
+                np.testing.assert_allclose(got["sq_jump"][c], want["sq_jump"][c], rtol=1e-4, atol=1e-9)
+            else:
+                # the two engines' states agree to the state tolerance only, and a squared jump amplifies that by
+                # |x| / |increment| (a move of 1e-2 from x ~ 1: an ulp of x is 1e-5 of the move).  Bound the difference
+                # by what the two traces themselves allow: | |a|^2 - |b|^2 | <= 2 |b| |a - b| + |a - b|^2 per step.
+                pg = np.concatenate([state[c][None], got["trace"][:, c]]).astype(np.float64)
+                pw = np.concatenate([state[c][None], want["trace"][:, c]]).astype(np.float64)
+                dg, dw = np.diff(pg, axis=0), np.diff(pw, axis=0)
+                gap2 = ((dg - dw) ** 2).sum(-1)
+                room = (2.0 * np.sqrt((dw ** 2).sum(-1) * gap2) + gap2).sum(0)  # [T]
+                err = np.abs(got["sq_jump"][c] - want["sq_jump"][c])
+                assert np.all(err <= 1e-4 * np.abs(want["sq_jump"][c]) + 1e-9 + 1.01 * room), \
+                    f"sq_jump of ladder {c} differs beyond what the two traces allow: {err.max():.3g}"
             continue
         d = int(bad[0])
         s_glob = step0 + d

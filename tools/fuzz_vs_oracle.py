@@ -3,7 +3,8 @@
     python tools/fuzz_vs_oracle.py [n_cases] [seed]
 
 Each case draws a target family with random parameters, a dimension in 1..104, a ladder of 1..256 temperatures, a
-proposal, swap mode / order / period, burn-in and a chain offset, runs both engines on the same external randoms and
+proposal, swap mode / order / period, burn-in and a chain offset, runs both engines on the same external randoms - and
+then once more in Philox mode, the production arithmetic (helpers.check_parity_philox) - and
 compares them over the FULL horizon with tests/helpers.check_parity: per-step traces identical (Normal: bit for bit),
 every differing Metropolis or swap decision PROVEN to sit inside the fp32 band of its threshold, both engines then
 restarted from the oracle's state; all four statistics exact on every agreeing segment."""
@@ -157,11 +158,21 @@ def main():
         except AssertionError as e:
             print(f"case {case:3d}: MISMATCH {e}")
             sys.exit(1)
+        # the same case on the PRODUCTION arithmetic: the kernel draws from Philox itself (hardware Box-Muller, scale folded
+        # into the radius, squared jumps from the proposal), the oracle restates the stream and exports what it drew
+        try:
+            fl += H.check_parity_philox(H.gpu_runner(spec, prop, dev), spec, prop, state=st, logp=lp, beta=beta, n_steps=N,
+                                        burn_in=burn, swap_every=se, seed=int(rng.integers(1, 1 << 40)),
+                                        chain_offset=kw["chain_offset"], step0=int(rng.integers(0, 50)),
+                                        swap_mode=kw["swap_mode"], swap_order=kw["swap_order"], segment=30)
+        except AssertionError as e:
+            print(f"case {case:3d}: MISMATCH (Philox mode) {e}")
+            sys.exit(1)
         flips += len(fl)
         tag = f"case {case:3d}: {spec.cls:30s} dim {dim:3d} T {T:3d} C {Cn:2d} {pk:13s} {order:10s} {mode:14s} N {N:2d} se {se} burn {burn}"
         print(tag, "ok", "" if not fl else f"({len(fl)} proven flip(s): {[(f[0], f[2]) for f in fl]})")
     print(f"{n_cases} cases agree; {flips} proven fp32-level decision flip(s) (MH or swap), every case compared to its end")
-    assert flips <= max(3, n_cases // 8), "too many decision flips for fp32-level differences"
+    assert flips <= max(3, n_cases // 4), "too many decision flips for fp32-level differences"
 
 
 if __name__ == "__main__":
