@@ -424,6 +424,9 @@ def main():
                         "so a ratio above 1 is possible and is NOT a roofline fraction."},
             "hbm_stream_inner1": inner1,
         })
+        if inner1 is not None and copy_gbps:
+            # the same box's plain device-to-device copy (torch's copy_ of 1 GiB) as a second denominator
+            inner1["frac_of_measured_copy"] = inner1["achieved"] / copy_gbps
         out = {
             "metric": "chain-MH-steps/sec", "value": value, "unit": "chain-MH-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
