@@ -621,12 +621,15 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   if (n_blocks > 0x7fffffffll) return PTRWM_E_ARG;
 
   // One launch covers a bounded amount of work (32-bit in-kernel counters; no multi-second kernels on a shared
-  // GPU): at most 2^20 steps and about 2^33 chain-steps (~0.3 s at 3e10/s).  Longer requests become back-to-back
+  // GPU): at most 2^16 steps and about 2^33 chain-steps (~0.2 s at 4e10/s).  Longer requests become back-to-back
   // launches on the same stream; step0 carries the swap schedule and the RNG position, so the split is invisible.
+  // 2^16 steps also bound how stale a launch-start decision can get: the verdict whether a replica's squared jumps may be
+  // taken from the proposal (proposals.h kJumpTrust) is re-taken at least that often - a coordinate cannot drift by more
+  // than a few hundred typical increments in between, which keeps the two definitions of the jump within ~1e-4 relative.
   const long long kMaxUnitsPerLaunch = 1ll << 33;
   long long kMaxStepsPerLaunch = kMaxUnitsPerLaunch / (args->n_chains * (long long)args->n_temps);
   if (kMaxStepsPerLaunch < 1) kMaxStepsPerLaunch = 1;
-  if (kMaxStepsPerLaunch > (1 << 20)) kMaxStepsPerLaunch = 1 << 20;
+  if (kMaxStepsPerLaunch > (1 << 16)) kMaxStepsPerLaunch = 1 << 16;
   const long long te = args->trace_every > 1 ? args->trace_every : 1;
   k.full.trace_every = (int)te;
   const long long reps = args->n_chains * args->n_temps;

@@ -410,6 +410,18 @@ def test_launch_split_and_resume_are_invisible(device):
     for k in ("n_accept", "swap_accept"):
         assert np.array_equal(one[k], a[k] + b[k])
     assert np.array_equal(one["last_swap_ordinal"], np.maximum(a["last_swap_ordinal"], b["last_swap_ordinal"]))
+    # a request longer than one launch may be (capi.hip: 2^16 steps) is cut by the library itself: the same again
+    spec2 = H.target_spec("rc15_d30")
+    prop2 = H.proposal_spec("Normal", 30, beta[:2], base_variance_scalar=2.38**2 / 30)
+    st2, lp2 = start_state(spec2, 2, 2, np.random.default_rng(1))
+    kw2 = dict(beta=beta[:2], burn_in=100, swap_every=7, seed=5, chain_offset=9)
+    long_run = gpu_run(spec2, prop2, device, state=st2, logp=lp2, step0=0, n_steps=70000, **kw2)
+    a2 = gpu_run(spec2, prop2, device, state=st2, logp=lp2, step0=0, n_steps=65536, **kw2)
+    b2 = gpu_run(spec2, prop2, device, state=a2["state"], logp=a2["logp"], step0=65536, n_steps=70000 - 65536, **kw2)
+    assert np.array_equal(long_run["state"], b2["state"]) and np.array_equal(long_run["logp"], b2["logp"])
+    for k in ("n_accept", "swap_accept"):
+        assert np.array_equal(long_run[k], a2[k] + b2[k])
+    assert np.allclose(long_run["sq_jump"], a2["sq_jump"] + b2["sq_jump"], rtol=1e-12)
 
 
 def test_chain_offset_makes_sharding_invisible(device):
