@@ -976,9 +976,9 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
   }
   if (live && l.q == 0) {
     ae->logp[rep] = lp;
-    if (ae->n_accept != nullptr && n_acc != 0u) ae->n_accept[rep] += (long long)n_acc;  // (kernel.h: RMW only where there is a delta)
+    if (ae->n_accept != nullptr && n_acc != 0u) count_add(&ae->n_accept[rep], (long long)n_acc);  // (kernel.h: only where there is a delta)
     if (ae->sq_jump != nullptr && sq != 0.0) ae->sq_jump[rep] += sq;
-    if (ae->swap_accept != nullptr && n_swap_acc != 0u) ae->swap_accept[rep] += (long long)n_swap_acc;
+    if (ae->swap_accept != nullptr && n_swap_acc != 0u) count_add(&ae->swap_accept[rep], (long long)n_swap_acc);
     if (ae->last_swap_ordinal != nullptr && last_event >= 0) {
       const long long ev = ae->first_swap_event + last_event;
       const long long ord = (ae->swap_order == PTRWM_ORDER_SEQUENTIAL) ? ev * (T - 1) + t + 1 : ev + 1;
