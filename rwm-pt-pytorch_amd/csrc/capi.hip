@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256) swap_sweep_kernel(const SweepArgs a) {
   __shared__ int s_landed[256];
   swap_decide(T, t, 0, t, a.swap_mode, a.swap_order, (int)(a.event_index & 1), a.beta, a.beta[t], us, s_l, s_u, s_landed,
               my_l, src, pair_acc, [] { __syncthreads(); },
-              __syncthreads_and(swap_threshold_ok(T, t, a.beta[t + 1 < T ? t + 1 : t], a.beta[t], my_l) ? 1 : 0) != 0);
+              __syncthreads_and(swap_threshold_ok(T, t, a.beta, a.beta[t], my_l) ? 1 : 0) != 0);
   if (live) s_src[tid] = src;
   __syncthreads();
   float *gs = a.state + chain * T * (long long)D;

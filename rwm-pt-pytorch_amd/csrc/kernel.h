@@ -115,8 +115,8 @@ __device__ __forceinline__ bool mh_accept(float beta_t, float lp_new, float lp, 
 // NaN and the swap is refused), the whole group takes the literal scan below for the whole launch - `plain`, voted once
 // per launch by swap_threshold_form(): a finite log-density stays finite (the Metropolis rule never accepts a proposal
 // whose log-density is -inf or NaN).
-__device__ __forceinline__ bool swap_threshold_ok(int T, int t, float beta_next, float beta_t, float lp) {
-  return (t >= T - 1 || sub_rn(beta_t, beta_next) > 0.0f) && lp > kNegInf;  // (NaN compares false)
+__device__ __forceinline__ bool swap_threshold_ok(int T, int t, const float *__restrict__ beta, float beta_t, float lp) {
+  return (t >= T - 1 || sub_rn(beta_t, beta[t + 1]) > 0.0f) && lp > kNegInf;  // (NaN compares false)
 }
 
 template <class Sync>
@@ -369,13 +369,6 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
   // run with fully coalesced dword loads (thread i takes elements i, i+n, ...) into its slab and each thread then
   // reads its own row (stride dim words: at most a 2-way bank conflict for even dim).  A direct per-thread row
   // read would touch 64 different cache lines per instruction.
-  // (the three per-thread scalars and the next rung's temperature are asked for FIRST: their loads are then in flight
-  // beside the state's instead of starting after the staging fence - one exposed HBM latency less per wave, which a
-  // one-step launch feels: 0.124 -> 0.119 ms; it was the next rung's temperature, read for the vote below, that waited)
-  float lp = a.logp[rep];
-  const float beta_t = a.beta[t];
-  const float tscale = a.temp_scale[t];
-  const float beta_next = a.beta[t + 1 < T ? t + 1 : t];
   float x[DP], y[DP];
   {
     const long long live_chains = (a.n_chains - chain0 < cpw) ? (a.n_chains - chain0) : cpw;
@@ -388,8 +381,11 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
 #pragma unroll
     for (int d = 0; d < DP; ++d) x[d] = (d < D0) ? row[d] : 0.0f;
   }
+  float lp = a.logp[rep];
+  const float beta_t = a.beta[t];
+  const float tscale = a.temp_scale[t];
   // one vote per launch: may the group's sequential sweeps take the threshold form?  (swap_decide)
-  const bool swap_plain = group_all(swap_threshold_ok(T, t, beta_next, beta_t, lp));
+  const bool swap_plain = group_all(swap_threshold_ok(T, t, a.beta, beta_t, lp));
   // may the proposal's own squared increment stand for |y - x|^2 for this replica?  (proposals.h kJumpTrust)
   bool jump_trusted = false;
   if constexpr (Proposal::kKnowsJump) {

@@ -681,11 +681,6 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
   // ---- state load: the group's live replicas are one contiguous run of elements: coalesced copy into the slab (as 32-bit
   // words: two per element in the F64 form, whose runs start 8-byte aligned, so the slab offset stage_head is even),
   // then every lane picks its quarter of its replica's row (row stride = dim)
-  // (per-thread scalars first: their loads fly beside the state's, kernel.h)
-  float lp = a.logp[rep];
-  const float beta_t = a.beta[t];
-  const float tscale = a.temp_scale[t];
-  const float beta_next = a.beta[t + 1 < T ? t + 1 : t];
   state_t x[W];
   float y[W];
   [[maybe_unused]] double yd[F64 ? W : 1];
@@ -703,6 +698,9 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
       if constexpr (F64) yd[j] = 0.0;
     }
   }
+  float lp = a.logp[rep];
+  const float beta_t = a.beta[t];
+  const float tscale = a.temp_scale[t];
   // may the proposal's own squared increment stand for |y - x|^2 for this replica?  (proposals.h kJumpTrust: the replica's
   // largest coordinate, over all four lanes, against the increment scale - the same verdict as the thread form's)
   bool jump_trusted = false;
@@ -715,7 +713,7 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
     jump_trusted = xmax <= kJumpTrust * Proposal::increment_scale(tscale, a.pp);
   }
   // one vote per launch: may the group's sequential sweeps take the threshold form?  (kernel.h swap_decide)
-  const bool swap_plain_here = swap_threshold_ok(T, t, beta_next, beta_t, lp);
+  const bool swap_plain_here = swap_threshold_ok(T, t, a.beta, beta_t, lp);
   const bool swap_plain = wide ? (__syncthreads_and(swap_plain_here ? 1 : 0) != 0) : (__builtin_amdgcn_ballot_w64(!swap_plain_here) == 0ull);
 
   const unsigned long long gchain = (unsigned long long)(a.chain_offset + chain);
