@@ -155,6 +155,32 @@ int32_t ptrwm_has_thread_variant(int32_t target_kind, int32_t proposal_kind, int
  * PTRWM_FORM_QUAD), or a negative status.  Introspection only: the forms give the same bits. */
 int32_t ptrwm_auto_form(int32_t target_kind, int32_t proposal_kind, int32_t dim, int32_t n_temps, int64_t n_chains);
 
+/* ---- short launches ------------------------------------------------------
+ * A launch of a few steps over a large batch (the reference's step()-at-a-time loops, rwm_gpu_optimized.py:456-457,
+ * pt_rwm_gpu_optimized.py:736-737) is HBM-bound; for it ptrwm_run has a STREAMING form of the one-thread-per-replica
+ * kernel: persistent wavefronts that walk the batch with the next group's state already in flight while the current one
+ * is stepped.  Same Philox words and arithmetic: the same bits as the classic kernel.  AUTO takes it for launches of
+ * <= 16 steps with at least two groups per resident wavefront, where the variant has a streaming twin (dims compiled
+ * in, n_temps <= 64) and the batch's layout allows whole aligned 16-byte vectors per group; OFF never; ON wherever twin
+ * and layout allow (tests, tuning).  Process-wide; returns the previous value, or PTRWM_E_ARG. */
+enum {
+  PTRWM_STREAM_AUTO = 0,
+  PTRWM_STREAM_OFF = 1,
+  PTRWM_STREAM_ON = 2
+};
+int32_t ptrwm_set_stream_mode(int32_t mode);
+/* 1 if the one-thread-per-replica variant for (target, proposal, dim) has a streaming twin, else 0. */
+int32_t ptrwm_has_stream_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim);
+
+/* Which kernel the calling thread's most recent successful ptrwm_run enqueued (introspection for tests and benchmark
+ * records; 0 before the first call). */
+enum {
+  PTRWM_LAUNCH_THREAD = 1, /* one thread per replica, classic form */
+  PTRWM_LAUNCH_QUAD = 2,   /* lane-split form */
+  PTRWM_LAUNCH_STREAM = 3  /* one thread per replica, streaming form */
+};
+int32_t ptrwm_last_launch_kind(void);
+
 /* Number of raw random numbers one MH proposal consumes from `ext_prop`
  * (NORMAL: dim normals; LAPLACE: dim uniforms in [0,1); UNIFORM_RADIUS: dim
  * normals then one uniform). */

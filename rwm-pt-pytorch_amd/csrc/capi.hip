@@ -100,6 +100,33 @@ static bool lane_split_is_faster(int dim, int n_temps, double w) {
 }
 
 static int g_kernel_form = PTRWM_FORM_AUTO;  // read / written with __atomic builtins (ptrwm_set_kernel_form may race with a launch)
+static int g_stream_mode = PTRWM_STREAM_AUTO;  // likewise (ptrwm_set_stream_mode)
+
+// ---- short launches: the streaming form of the one-thread-per-replica kernel (kernel.h STREAM) ---------------------------
+// A launch of a few Metropolis steps over a large batch - the reference's step()-at-a-time loops
+// (rwm_gpu_optimized.py:456-457, pt_rwm_gpu_optimized.py:736-737), split steps, the harness's benchmark_performance - is
+// bound by HBM, not by instruction issue: the state is read, stepped once and written back.  The classic kernel gives every
+// wave ONE group: load, compute, store, exit - the three phases of a wave do not overlap and a SIMD's resident waves run
+// them nearly in lock-step.  The streaming form keeps as many waves as the device holds resident and lets each walk many
+// groups with the next group's state already in flight.  Same Philox words, same arithmetic, same canonical order:
+// bit-identical to the classic kernel (tests: test_launch_split_and_resume_are_invisible).  AUTO takes it when
+//   - the launch is short (<= kStreamMaxSteps steps: beyond that the step loop dominates and the classic kernel's extra
+//     resident wave per SIMD is worth more than the overlap),
+//   - there is something to stream (>= kStreamMinRounds groups per resident wave), and
+//   - the layout allows whole aligned 16-byte vectors per group (every group full: n_chains a multiple of the ladders per
+//     wave; cpw * n_temps * dim a multiple of 4 and cpw * n_temps even; state and sq_jump 16-byte aligned) - otherwise the
+//     classic kernel's general staging.
+constexpr int kStreamMaxSteps = 16;
+constexpr int kStreamMinRounds = 2;
+
+// what the calling thread's most recent ptrwm_run launched (ptrwm_last_launch_kind: tests and the benchmark's record)
+static thread_local int t_last_launch_kind = 0;
+
+static bool stream_layout_ok(const ptrwm_run_args *args, int dim, int cpw) {
+  return args->n_temps <= 64 && args->n_chains % cpw == 0 && ((long long)cpw * args->n_temps * dim) % 4 == 0 &&
+         (cpw * args->n_temps) % 2 == 0 && (reinterpret_cast<uintptr_t>(args->state) & 15u) == 0 &&
+         (reinterpret_cast<uintptr_t>(args->sq_jump) & 15u) == 0;
+}
 
 // SIMDs of the current device (compute units x 4), asked once per device: the form rule is stated in wavefronts per SIMD,
 // so a partitioned or CU-masked device (or another CDNA part) gets the rule scaled to what it really has.
@@ -484,6 +511,19 @@ int32_t ptrwm_set_kernel_form(int32_t form) {
   return __atomic_exchange_n(&g_kernel_form, form, __ATOMIC_RELAXED);
 }
 
+int32_t ptrwm_set_stream_mode(int32_t mode) {
+  if (mode != PTRWM_STREAM_AUTO && mode != PTRWM_STREAM_OFF && mode != PTRWM_STREAM_ON) return PTRWM_E_ARG;
+  return __atomic_exchange_n(&g_stream_mode, mode, __ATOMIC_RELAXED);
+}
+
+int32_t ptrwm_last_launch_kind(void) { return t_last_launch_kind; }
+
+int32_t ptrwm_has_stream_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim) {
+  if (ptrwm_has_thread_variant(target_kind, proposal_kind, dim) == 0) return 0;
+  const int dpi = width_index_for_dim(dim);
+  return has_stream_variant(kWidths[dpi].dp, kWidths[dpi].exact) ? 1 : 0;
+}
+
 int32_t ptrwm_has_quad_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim, int32_t n_temps) {
   if (target_kind < 0 || target_kind >= PTRWM_TARGET_COUNT) return 0;
   if (proposal_kind < 0 || proposal_kind >= PTRWM_PROPOSAL_COUNT) return 0;
@@ -528,7 +568,7 @@ int32_t ptrwm_has_variant(int32_t target_kind, int32_t proposal_kind, int32_t di
 }
 
 int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *proposal, const ptrwm_run_args *args,
-                  void *stream) {
+                  void *hip_stream) {
   if (proposal == nullptr || args == nullptr) return PTRWM_E_NULL;
   if (int rc = check_target(target)) return rc;
   if (args->struct_size != sizeof(ptrwm_run_args)) return PTRWM_E_STRUCT;
@@ -616,6 +656,18 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   k.full.trace_temps = args->trace_temps;
   k.full.n_raw_ext = ptrwm_ext_raw_per_step(proposal->kind, target->dim);
 
+  // the streaming form for short launches of the one-thread-per-replica kernel (see kStreamMaxSteps above)
+  bool stream = false;
+  if (!quad && !full && has_stream_variant(kWidths[dpi].dp, kWidths[dpi].exact) && stream_layout_ok(args, target->dim, k.chains_per_wave)) {
+    const int mode = __atomic_load_n(&g_stream_mode, __ATOMIC_RELAXED);
+    if (mode == PTRWM_STREAM_ON) {
+      stream = true;
+    } else if (mode == PTRWM_STREAM_AUTO && args->n_steps <= kStreamMaxSteps) {
+      const long long resident = device_simds() * stream_waves_per_simd(kWidths[dpi].dp);
+      stream = args->n_chains / k.chains_per_wave >= kStreamMinRounds * resident;
+    }
+  }
+
   const long long n_waves = (args->n_chains + k.chains_per_wave - 1) / k.chains_per_wave;
   const long long n_blocks = wide ? n_waves : (n_waves + kWavesPerBlock - 1) / kWavesPerBlock;  // wide: one group per block
   if (n_blocks > 0x7fffffffll) return PTRWM_E_ARG;
@@ -630,6 +682,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   long long kMaxStepsPerLaunch = kMaxUnitsPerLaunch / (args->n_chains * (long long)args->n_temps);
   if (kMaxStepsPerLaunch < 1) kMaxStepsPerLaunch = 1;
   if (kMaxStepsPerLaunch > (1 << 16)) kMaxStepsPerLaunch = 1 << 16;
+  t_last_launch_kind = quad ? PTRWM_LAUNCH_QUAD : (stream ? PTRWM_LAUNCH_STREAM : PTRWM_LAUNCH_THREAD);
   const long long te = args->trace_every > 1 ? args->trace_every : 1;
   k.full.trace_every = (int)te;
   const long long reps = args->n_chains * args->n_temps;
@@ -654,7 +707,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
     // traced steps are those whose step_counter is a multiple of trace_every: rows before this launch
     k.full.trace_row0 = args->trace_row0 + (step0 / te - args->step0 / te);
     k.full.steps_to_trace = (int)(te - step0 % te);
-    const hipError_t err = fn(k, (unsigned)n_blocks, full, (hipStream_t)stream);
+    const hipError_t err = fn(k, (unsigned)n_blocks, full ? kRunFull : (stream ? kRunStream : kRunProd), (hipStream_t)hip_stream);
     if (err != hipSuccess) return PTRWM_E_LAUNCH;
     done += n;
   }

@@ -30,8 +30,15 @@ constexpr int kWavesPerBlock = kBlockThreads / 64;
 // launch but are touched only in swap events and the epilogue (parked in LDS to keep them out of the VGPR budget
 // of the MH part: without that the compiler spilled five VGPRs to scratch, 42 MB of HBM traffic per launch)
 constexpr int kLdsExtraPerThread = 6;  // s_l, s_u, landed (swap-event scratch); c3, swap count, last event (whole launch)
-constexpr unsigned step_kernel_lds_bytes(int threads, int dp) {
-  return (unsigned)(threads * (dp + kLdsExtraPerThread)) * 4u;
+// (the streaming form, STREAM below, keeps TWO slabs of rows per wave: the one its current group lives in and the one the
+// next group's state is landing in)
+// and two small landing zones for the next group's log-densities (one float per thread) and squared-jump sums (one double)
+constexpr int kLdsStreamStatPerThread = 3;  // floats per thread and landing zone
+constexpr int lds_floats_per_thread(int dp, bool stream) {
+  return (stream ? 2 * dp + 2 * kLdsStreamStatPerThread : dp) + kLdsExtraPerThread;
+}
+constexpr unsigned step_kernel_lds_bytes(int threads, int dp, bool stream = false) {
+  return (unsigned)(threads * lds_floats_per_thread(dp, stream)) * 4u;
 }
 
 // Arguments only the fixture / trace variant of the kernel (FULL = true) reads.  Keeping them out
@@ -319,24 +326,131 @@ constexpr int min_waves_per_simd(int dp) {
   return dp <= 30 ? PTRWM_WAVES_SMALL : (dp <= 44 ? PTRWM_WAVES_40 : (dp <= 64 ? PTRWM_WAVES_MID : 1));
 }
 
+// The streaming form (STREAM, below) keeps two slabs of rows per wave in LDS: fewer waves per SIMD fit (and each gets the
+// registers of that residency).
+constexpr int stream_waves_per_simd(int dp) {  // what two slabs per wave leave room for in 160 KB of LDS per CU, at most 4
+  return dp <= 10 ? 4 : (dp <= 20 ? 3 : (dp <= 30 ? 2 : 1));
+}
+
+// (the register budget it is compiled for: never that of ONE wave per SIMD - 512 registers invite AGPR copies, the regime
+// tools/kernel_stats.py --check keeps every kernel out of - even where LDS admits no second wave)
+constexpr int stream_register_waves(int dp) { return stream_waves_per_simd(dp) < 2 ? 2 : stream_waves_per_simd(dp); }
+
 // DP    compile-time width of the per-thread register arrays (>= dim)
 // EXACT dim == DP is known at compile time: every per-dimension predicate folds away.  Otherwise
 //       dim is a wave-uniform run-time value, re-read (opaquely) every step so the compiler tests
 //       `d < dim` with one scalar compare in place instead of hoisting DP booleans into SGPRs.
 // FULL  fixture/trace variant: external randoms, per-step trace and accept-flag outputs.
-template <class Target, class Proposal, int DP, bool EXACT, bool FULL>
-__global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_step_kernel(const KArgs a) {
+template <class Target, class Proposal, int DP, bool EXACT, bool FULL, bool STREAM = false>
+__global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(DP) : min_waves_per_simd(DP)) ptrwm_step_kernel(const KArgs a) {
+  static_assert(!(STREAM && FULL), "the streaming form is a production kernel: no fixture / trace arguments");
   const int T = a.n_temps;
   const int D0 = EXACT ? DP : a.dim;
   const int cpw = a.chains_per_wave;
   // An exchange group is one wavefront holding cpw = 64 / T whole ladders (T <= 64, "narrow": a workgroup is four
   // independent groups), or ceil(T / 64) wavefronts = the whole workgroup holding one ladder ("wide", cpw = 1).
   // Thread tid of its group is (cw, t) with tid = cw * T + t either way.
-  const bool wide = T > 64;  // grid-uniform
+  const bool wide = !STREAM && T > 64;  // grid-uniform (the streaming form serves narrow ladders only)
   const int wave = wave_in_block();  // (an SGPR for the whole launch: thread_index_now)
   const int tid = wide ? (int)threadIdx.x : (int)(threadIdx.x & 63);
-  const long long chain0 = (wide ? (long long)blockIdx.x : (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * cpw;
-  if (chain0 >= a.n_chains) return;  // narrow only (wave-uniform; narrow waves never meet at a workgroup barrier)
+  // The group this wave (narrow) / workgroup (wide) works on.  Classic form: one group per wave, fixed by the grid.
+  // Streaming form: the grid is sized to the device (capi.hip) and every wave walks the groups gw, gw + stride, ... with
+  // the NEXT group's state, log-densities and squared-jump sums already on their way from HBM while it computes (below).
+  // (the classic form derives it from threadIdx.x, as it always did: its register allocation at the 128-VGPR cap follows
+  // every such detail; the streaming form carries it across groups in scalar registers)
+  long long group = STREAM ? (long long)blockIdx.x * kWavesPerBlock + wave
+                           : (wide ? (long long)blockIdx.x : (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+  [[maybe_unused]] const long long n_groups = STREAM ? a.n_chains / cpw : 0;  // (streaming: every group is whole, capi.hip)
+  [[maybe_unused]] const long long group_stride = STREAM ? (long long)gridDim.x * kWavesPerBlock : 0;
+  if (STREAM ? (group >= n_groups) : (group * cpw >= a.n_chains)) return;  // narrow only (wave-uniform; narrow waves never meet at a workgroup barrier)
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  // ---- streaming form: LDS-DMA double buffering ---------------------------------------------------------------------
+  // A group's state is one run of cpw * T * dim floats, 16-byte aligned and a whole number of 16-byte vectors (capi.hip
+  // takes the classic kernel otherwise).  Each wave owns TWO slabs: while the group in slab `cur` is being stepped, the
+  // next group's run is on its way from HBM straight into the other slab (global_load_lds_dwordx4: 1 KiB per wave
+  // instruction, no VGPR destination - the step keeps every register it has in the classic kernel), issued right after
+  // the current group's rows have been picked up and waited for (a counted vmcnt placed by the compiler: the builtin is
+  // a tracked memory operation) only when the next group's rows are read - the current group's stores, issued later,
+  // stay in flight behind it.  HBM reads, the Metropolis step and HBM writes of different groups overlap inside ONE
+  // wave, not only across waves.  The next group's log-densities and squared-jump sums travel the same way into two
+  // small landing zones: an ordinary load to a VGPR anywhere in this loop would make the compiler drain every
+  // outstanding DMA and store (vmcnt(0)) at its first use.
+  // LDS of a wave, in floats: [slab 0: 64 DP][slab 1: 64 DP][swap scratch + parked words: 6 x 64][zone 0: 3 x 64][zone 1]
+  typedef float pf_vec4 __attribute__((ext_vector_type(4)));
+  constexpr int NV = STREAM ? (DP + 3) / 4 : 1;  // 16-byte vectors per lane and group
+  constexpr int kWaveFloats = 64 * lds_floats_per_thread(DP, STREAM);
+  constexpr int kZone0 = 64 * (2 * DP + kLdsExtraPerThread), kZoneFloats = 64 * kLdsStreamStatPerThread;
+  [[maybe_unused]] int cur = 0;  // which slab / landing zone holds the current group (streaming form; wave-uniform)
+  typedef const __attribute__((address_space(1))) void *dma_src;
+  typedef __attribute__((address_space(3))) void *dma_dst;
+  [[maybe_unused]] auto prefetch = [&](long long g, int slab) {
+    const int tid = thread_index_now(wave) & 63;  // (re-derived: no per-lane address parts kept, or spilled, across the step)
+    const kargs_ptr ap = late_args();             // (and the array pointers are loaded here, not held in SGPRs across it)
+    const int n_vec = (cpw * T * D0) >> 2;
+    const int n_live = cpw * T;
+    float *const wbase = s_dyn + wave * kWaveFloats;
+    // log-densities: one dword per lane (idle lanes re-read replica 0 of the group)
+    const long long r0 = g * n_live;
+    float *const zone = wbase + kZone0 + slab * kZoneFloats;
+    __builtin_amdgcn_global_load_lds((dma_src)(ap->logp + r0 + (tid < n_live ? tid : 0)), (dma_dst)(uintptr_t)zone, 4, 0, 0);
+    // squared-jump sums: 16 bytes = two doubles per lane (n_live is even, capi.hip)
+    if (ap->sq_jump != nullptr && 2 * tid < n_live)
+      __builtin_amdgcn_global_load_lds((dma_src)(ap->sq_jump + r0 + 2 * tid), (dma_dst)(uintptr_t)(zone + 64), 16, 0, 0);
+    const pf_vec4 *__restrict__ gv = reinterpret_cast<const pf_vec4 *>(ap->state + g * cpw * T * (long long)D0);
+    float *const dst = wbase + slab * (64 * DP);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = tid + 64 * k;
+      if (v < n_vec) __builtin_amdgcn_global_load_lds((dma_src)(gv + v), (dma_dst)(uintptr_t)(dst + 256 * k), 16, 0, 0);
+    }
+  };
+  // (streaming form: what depends on the thread's temperature only is loaded ONCE, before the first DMA is issued - any
+  // ordinary global load behind an LDS-DMA makes the compiler drain the DMA at the load's first use, which would put the
+  // next group's HBM latency back in front of the current group's step)
+  [[maybe_unused]] float beta_t_s = 0.0f, tscale_s = 0.0f;
+  [[maybe_unused]] bool pair_ordered_s = false;  // swap_threshold_ok's condition on the temperatures
+  // Outgoing results of the group just finished wait in registers until the NEXT group's rows have been picked up, and
+  // are stored then (flush_pending): at the top of an iteration the only vector-memory operations that can still be
+  // outstanding are the DMA of the group about to be stepped and the stores issued a whole step earlier - so the wait for
+  // the DMA is a plain vmcnt(0) that never waits for a store just issued.
+  [[maybe_unused]] pf_vec4 pend_o[NV];
+  [[maybe_unused]] float pend_lp = 0.0f;
+  [[maybe_unused]] unsigned pend_n_acc = 0u, pend_n_swap = 0u;
+  [[maybe_unused]] double pend_sq = 0.0;
+  [[maybe_unused]] long long pend_ord = 0, pend_group = 0;
+  [[maybe_unused]] bool pend_sq_on = false, pend_ord_on = false, have_pending = false;
+  [[maybe_unused]] auto flush_pending = [&]() {
+    const kargs_ptr ap = late_args();
+    const int tid = thread_index_now(wave) & 63;
+    const int n_live = cpw * T;
+    const int n_vec = (n_live * D0) >> 2;
+    pf_vec4 *__restrict__ gv = reinterpret_cast<pf_vec4 *>(ap->state + pend_group * n_live * (long long)D0);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = tid + 64 * k;
+      if (v < n_vec) gv[v] = pend_o[k];
+    }
+    if (tid < n_live) {
+      const long long r = pend_group * n_live + tid;
+      ap->logp[r] = pend_lp;
+      // statistics: only where the launch has something to add (kernel epilogue below)
+      if (ap->n_accept != nullptr && pend_n_acc != 0u) count_add(&ap->n_accept[r], (long long)pend_n_acc);
+      if (pend_sq_on) ap->sq_jump[r] = pend_sq;
+      if (ap->swap_accept != nullptr && pend_n_swap != 0u) count_add(&ap->swap_accept[r], (long long)pend_n_swap);
+      // (the same maximum as the classic kernel's compare-and-store, as a no-return atomic at the L2: no load)
+      if (pend_ord_on) (void)__hip_atomic_fetch_max(&ap->last_swap_ordinal[r], pend_ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  if constexpr (STREAM) {
+    const int cw_s = tid / T;
+    const int t_s = cw_s < cpw ? tid - cw_s * T : 0;
+    beta_t_s = a.beta[t_s];
+    tscale_s = a.temp_scale[t_s];
+    pair_ordered_s = swap_threshold_ok(T, t_s, a.beta, beta_t_s, 0.0f);
+    prefetch(group, 0);
+  }
+  do {
+  const long long chain0 = group * cpw;
   const int cw_raw = tid / T;
   const int t_raw = tid - cw_raw * T;
   const bool live = (cw_raw < cpw) && (chain0 + cw_raw < a.n_chains);
@@ -350,8 +464,10 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
   // s_stage: one row of up to DP floats per thread; the group packs its live replicas' rows back to back (row
   // stride = dim) for the coalesced state load / store and exchanges rows through it in a swap.
   // s_l / s_u / landed (behind the rows): per-thread log-density, swap uniform and swap outcome of a swap sweep.
-  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-  float *const s_stage = s_dyn + (wide ? 0 : (int)(threadIdx.x >> 6) * (64 * (DP + kLdsExtraPerThread)));
+  // (streaming form: the slab of the current group; the swap scratch and the parked words sit behind BOTH slabs)
+  float *const s_stage = STREAM ? s_dyn + wave * kWaveFloats + cur * (64 * DP)
+                                : s_dyn + (wide ? 0 : (int)(threadIdx.x >> 6) * (64 * (DP + kLdsExtraPerThread)));
+  [[maybe_unused]] float *const s_extra = s_dyn + wave * kWaveFloats + 2 * (64 * DP);  // streaming form only
   // group-wide ordering of LDS accesses: the group is one wave (narrow) or the workgroup (wide)
   auto sync_group = [&]() {
     if (wide) {
@@ -375,17 +491,38 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     const int stage_total = (int)live_chains * T * D0;  // floats of this group's run
     float *__restrict__ gs = a.state + chain0 * T * (long long)D0;
     const int nthr = wide ? ((T + 63) & ~63) : 64;  // threads of the group = of the workgroup
-    stage_copy<true>(s_stage, gs, stage_total, tid, nthr);
+    int row_head = 0;
+    if constexpr (!STREAM) {
+      stage_copy<true>(s_stage, gs, stage_total, tid, nthr);
+      row_head = stage_head(gs);
+    }
+    // (streaming form: the run is landing in slab `cur` by LDS-DMA.  The compiler does not order LDS reads behind it:
+    // this wait does - every DMA of this wave, and nothing younger than a whole step, see flush_pending)
+    if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     sync_group();
-    const float *row = s_stage + stage_head(gs) + (live ? tid : 0) * D0;  // idle threads shadow row 0 = replica (chain0, 0)
+    const float *row = s_stage + row_head + (live ? tid : 0) * D0;  // idle threads shadow row 0 = replica (chain0, 0)
 #pragma unroll
     for (int d = 0; d < DP; ++d) x[d] = (d < D0) ? row[d] : 0.0f;
   }
-  float lp = a.logp[rep];
-  const float beta_t = a.beta[t];
-  const float tscale = a.temp_scale[t];
+  float lp;
+  [[maybe_unused]] double sq_old = 0.0;
+  if constexpr (STREAM) {
+    {
+      const float *zone = s_dyn + wave * kWaveFloats + kZone0 + cur * kZoneFloats;
+      lp = zone[tid];
+      if (a.sq_jump != nullptr) sq_old = reinterpret_cast<const double *>(zone + 64)[tid < cpw * T ? tid : 0];
+    }
+    // the previous group's results leave now, and behind them the next group's DMA is issued: the other slab is free,
+    // the previous group's outgoing rows were read back into pend_o before this group began
+    if (have_pending) flush_pending();
+    if (group + group_stride < n_groups) prefetch(group + group_stride, cur ^ 1);
+  } else {
+    lp = a.logp[rep];
+  }
+  const float beta_t = STREAM ? beta_t_s : a.beta[t];
+  const float tscale = STREAM ? tscale_s : a.temp_scale[t];
   // one vote per launch: may the group's sequential sweeps take the threshold form?  (swap_decide)
-  const bool swap_plain = group_all(swap_threshold_ok(T, t, a.beta, beta_t, lp));
+  const bool swap_plain = group_all(STREAM ? (pair_ordered_s && lp > kNegInf) : swap_threshold_ok(T, t, a.beta, beta_t, lp));
   // may the proposal's own squared increment stand for |y - x|^2 for this replica?  (proposals.h kJumpTrust)
   bool jump_trusted = false;
   if constexpr (Proposal::kKnowsJump) {
@@ -407,7 +544,7 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     // parked in LDS (see step_kernel_lds_bytes): the Philox word with the temperature index, the number of accepted
     // swaps of pair (t, t+1) and the index within this launch of the last swap event in which it accepted
     const int gt = wide ? ((T + 63) & ~63) : 64;
-    int *const park = reinterpret_cast<int *>(s_stage + gt * (DP + 3)) + tid;
+    int *const park = reinterpret_cast<int *>(STREAM ? s_extra + 3 * gt : s_stage + gt * (DP + 3)) + tid;
     park[0] = (int)c3_base;
     park[gt] = 0;
     park[2 * gt] = -1;
@@ -514,10 +651,11 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       const int tid_s = thread_index_now(wave);
       const int slot = wide ? tid_s : (tid_s & 63);  // this thread's slot in s_l / s_u and its row in s_stage
       const int group_threads = wide ? ((T + 63) & ~63) : 64;
-      float *const rows = s_dyn + (wide ? 0 : (tid_s >> 6) * (64 * (DP + kLdsExtraPerThread)));
-      float *const s_l = rows + group_threads * DP;
+      float *const rows = STREAM ? s_dyn + wave * kWaveFloats + cur * (64 * DP)
+                                 : s_dyn + (wide ? 0 : (tid_s >> 6) * (64 * (DP + kLdsExtraPerThread)));
+      float *const s_l = STREAM ? s_dyn + wave * kWaveFloats + 2 * (64 * DP) : rows + group_threads * DP;
       float *const s_u = s_l + group_threads;
-      int *const park = reinterpret_cast<int *>(rows + group_threads * (DP + 3)) + slot;
+      int *const park = reinterpret_cast<int *>(s_l + 3 * group_threads) + slot;
       const uint32_t c3_s = (uint32_t)park[0];
       const int t = (int)(c3_s & 0xffu);  // the temperature index, as the Philox counter holds it
       const int base = live ? slot - t : 0;            // slot of temperature 0 of this thread's ladder
@@ -594,9 +732,15 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     const bool wide2 = T2 > 64;
     const int tx2 = thread_index_now(wave);
     const int tid2 = wide2 ? tx2 : (tx2 & 63);
-    float *const rows2 = s_dyn + (wide2 ? 0 : wave * (64 * (DP + kLdsExtraPerThread)));
-    const long long bid = (long long)fresh_dim<false>((int)blockIdx.x);  // re-read here, not carried in a VGPR
-    const long long c0 = (wide2 ? bid : bid * kWavesPerBlock + wave) * cpw2;
+    float *const rows2 = STREAM ? s_dyn + wave * kWaveFloats + cur * (64 * DP)
+                                : s_dyn + (wide2 ? 0 : wave * (64 * (DP + kLdsExtraPerThread)));
+    long long c0;
+    if constexpr (STREAM) {
+      c0 = group * cpw2;
+    } else {
+      const long long bid = (long long)fresh_dim<false>((int)blockIdx.x);  // re-read here, not carried in a VGPR
+      c0 = (wide2 ? bid : bid * kWavesPerBlock + wave) * cpw2;
+    }
     const long long n_chains2 = ae->n_chains;
     const long long live_chains = (n_chains2 - c0 < cpw2) ? (n_chains2 - c0) : cpw2;
     const int stage_total = (int)live_chains * T2 * D2;
@@ -612,18 +756,42 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
     }
     sync_group();
     const int nthr = wide2 ? ((T2 + 63) & ~63) : 64;
-    stage_copy<false>(rows2, gs, stage_total, tid2, nthr);
+    if constexpr (STREAM) {
+      // whole aligned vectors only (capi.hip): slab -> registers now, registers -> HBM in flush_pending
+      const pf_vec4 *__restrict__ lv = reinterpret_cast<const pf_vec4 *>(rows2);
+      const int n_vec = stage_total >> 2;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int v = tid2 + 64 * k;
+        if (v < n_vec) pend_o[k] = lv[v];
+      }
+    } else {
+      stage_copy<false>(rows2, gs, stage_total, tid2, nthr);
+    }
   }
   if (live) {
     const int tid_o = thread_index_now(wave);
     const int T_o = fresh_dim<false>(T);
     const long long rep = c0_out * T_o + (T_o > 64 ? tid_o : (tid_o & 63));  // live: replica index in group == tid
     const int gt_o = T_o > 64 ? ((T_o + 63) & ~63) : 64;
-    const int *const park = reinterpret_cast<const int *>(s_dyn + (T_o > 64 ? 0 : (tid_o >> 6) * (64 * (DP + kLdsExtraPerThread)))
-                                                          + gt_o * (DP + 3)) + (T_o > 64 ? tid_o : (tid_o & 63));
+    const int *const park = reinterpret_cast<const int *>(STREAM ? s_dyn + wave * kWaveFloats + 2 * (64 * DP) + 3 * 64
+                                                                 : s_dyn + (T_o > 64 ? 0 : (tid_o >> 6) * (64 * (DP + kLdsExtraPerThread)))
+                                                                       + gt_o * (DP + 3)) + (T_o > 64 ? tid_o : (tid_o & 63));
     const int t = park[0] & 0xff;
     const unsigned n_swap_acc = (unsigned)park[gt_o];
     const int last_event = park[2 * gt_o];
+    if constexpr (STREAM) {
+      // handed to flush_pending (the old squared-jump sum came in with the prefetch: the same double addition as the classic
+      // kernel's read-modify-write, without a load)
+      pend_lp = lp;
+      pend_n_acc = n_acc;
+      pend_n_swap = n_swap_acc;
+      pend_sq_on = ae->sq_jump != nullptr && sq != 0.0;
+      pend_sq = sq_old + sq;
+      pend_ord_on = ae->last_swap_ordinal != nullptr && last_event >= 0;
+      const long long ev = ae->first_swap_event + last_event;
+      pend_ord = (ae->swap_order == PTRWM_ORDER_SEQUENTIAL) ? ev * (T_o - 1) + t + 1 : ev + 1;
+    } else {
     ae->logp[rep] = lp;
     // statistics: read-modify-write only where this launch has something to add (a launch without a swap event - nine in
     // ten at one step per launch - then leaves the swap counters' cache lines alone)
@@ -637,7 +805,15 @@ __global__ void __launch_bounds__(kBlockThreads, min_waves_per_simd(DP)) ptrwm_s
       const long long ord = (ae->swap_order == PTRWM_ORDER_SEQUENTIAL) ? ev * (T_o - 1) + t + 1 : ev + 1;
       if (ord > ae->last_swap_ordinal[rep]) ae->last_swap_ordinal[rep] = ord;
     }
+    }
   }
+  if constexpr (!STREAM) break;
+  pend_group = group;
+  have_pending = true;
+  group += group_stride;
+  cur ^= 1;
+  } while (group < n_groups);
+  if constexpr (STREAM) flush_pending();
 }
 
 // ---- standalone log-density kernel (unit parity of the targets; initial log-density) ----

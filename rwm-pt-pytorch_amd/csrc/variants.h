@@ -58,7 +58,14 @@ inline int width_index_for_dim(int dim) {
   return best;
 }
 
-using RunLaunchFn = hipError_t (*)(const KArgs &, unsigned grid, bool full, hipStream_t);
+// mode: which twin of the variant runs - the production kernel, the fixture / trace kernel (FULL), or the streaming form of
+// the production kernel (kernel.h STREAM: persistent waves that prefetch their next group; sizes its own grid, `grid` is
+// ignored; hipErrorNotSupported where the variant has no streaming twin)
+enum { kRunProd = 0, kRunFull = 1, kRunStream = 2 };
+using RunLaunchFn = hipError_t (*)(const KArgs &, unsigned grid, int mode, hipStream_t);
+// Streaming twins exist for the one-thread-per-replica kernels with dim compiled in (the dims the reference's experiments
+// run); every other shape takes the classic kernel whatever the launch length.
+constexpr bool has_stream_variant(int dp, bool exact) { return exact && dp <= 64; }
 using LogpLaunchFn = hipError_t (*)(const float *, float *, long long, int, const TParams &, hipStream_t);
 
 struct TargetVariants {
@@ -82,8 +89,61 @@ inline hipError_t raise_dynamic_lds(const void *kfull, const void *kprod, int ca
   return hipSuccess;
 }
 
+// compute units of the current device, asked once per device (0 on error)
+inline int device_cus() {
+  constexpr int kMaxDevices = 64;
+  static int cached[kMaxDevices];  // 0 = not asked yet (a race merely asks twice)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
+  int n = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 0;
+    __atomic_store_n(&cached[dev], n, __ATOMIC_RELAXED);
+  }
+  return n;
+}
+
+// The streaming twin: a grid sized to the device - as many workgroups as are resident at once (occupancy of THIS kernel on
+// THIS device, asked once), trimmed so that every wave walks the same number of groups (+-1).
 template <class Target, class Proposal, int DP, bool EXACT>
-hipError_t launch_run(const KArgs &a, unsigned grid, bool full, hipStream_t stream) {
+hipError_t launch_run_stream(const KArgs &a, hipStream_t stream) {
+  if constexpr (!has_stream_variant(DP, EXACT)) {
+    return hipErrorNotSupported;
+  } else {
+    if (a.n_temps > 64) return hipErrorNotSupported;
+    auto ks = ptrwm_step_kernel<Target, Proposal, DP, EXACT, false, true>;
+    const unsigned lds = step_kernel_lds_bytes(kBlockThreads, DP, true);
+    constexpr int kMaxDevices = 64;
+    static int wg_per_cu[kMaxDevices];  // 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    int per_cu = __atomic_load_n(&wg_per_cu[dev], __ATOMIC_RELAXED);
+    if (per_cu == 0) {
+      if (lds > 48u * 1024u) {
+        const hipError_t e = hipFuncSetAttribute((const void *)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+      }
+      const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ks, kBlockThreads, lds);
+      if (e != hipSuccess) return e;
+      if (per_cu < 1) return hipErrorInvalidConfiguration;
+      __atomic_store_n(&wg_per_cu[dev], per_cu, __ATOMIC_RELAXED);
+    }
+    const int cus = device_cus();
+    if (cus <= 0) return hipErrorInvalidDevice;
+    const long long n_groups = a.n_chains / a.chains_per_wave;
+    const long long max_waves = (long long)cus * per_cu * kWavesPerBlock;
+    const long long rounds = (n_groups + max_waves - 1) / max_waves;
+    const long long waves = (n_groups + rounds - 1) / rounds;
+    const unsigned grid = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(ks, dim3(grid), dim3(kBlockThreads), lds, stream, a);
+    return hipGetLastError();
+  }
+}
+
+template <class Target, class Proposal, int DP, bool EXACT>
+hipError_t launch_run(const KArgs &a, unsigned grid, int mode, hipStream_t stream) {
+  if (mode == kRunStream) return launch_run_stream<Target, Proposal, DP, EXACT>(a, stream);
+  const bool full = mode == kRunFull;
   // narrow ladders: four independent one-wave groups per workgroup; wide ones (n_temps > 64): as many waves as
   // the ladder needs
   const unsigned block = a.n_temps > 64 ? (unsigned)((a.n_temps + 63) & ~63) : (unsigned)kBlockThreads;
@@ -187,7 +247,9 @@ constexpr int quad_min_own(int w, int dexact) {
 }
 
 template <class Target, class Proposal, int W, int DEXACT, int MAXT, bool F64 = false>
-hipError_t launch_run_quad(const KArgs &a, unsigned grid, bool full, hipStream_t stream) {
+hipError_t launch_run_quad(const KArgs &a, unsigned grid, int mode, hipStream_t stream) {
+  if (mode == kRunStream) return hipErrorNotSupported;  // the lane-split form has no streaming twin
+  const bool full = mode == kRunFull;
   // narrow ladders (4 T <= 64): four independent one-wave groups per workgroup; wide ones: one ladder per workgroup
   const unsigned block = (unsigned)quad_block_threads(a.n_temps);
   if ((int)block > MAXT) return hipErrorInvalidConfiguration;

@@ -47,6 +47,9 @@ ORDER_EVEN_ODD = 1
 # form of the fused step kernel (ptrwm_set_kernel_form): a speed choice only, results are bit-identical
 FORM_AUTO, FORM_THREAD, FORM_QUAD = 0, 1, 2
 
+# short launches (ptrwm_set_stream_mode): the streaming form of the one-thread-per-replica kernel; same bits either way
+STREAM_AUTO, STREAM_OFF, STREAM_ON = 0, 1, 2
+
 SWAP_MODES = {"exchange": SWAP_EXCHANGE, "reference_copy": SWAP_REFERENCE_COPY}
 SWAP_ORDERS = {"sequential": ORDER_SEQUENTIAL, "even_odd": ORDER_EVEN_ODD}
 
@@ -122,6 +125,9 @@ SYMBOLS = {
     "ptrwm_ext_raw_per_step": (C.c_int32, [C.c_int32, C.c_int32]),
     "ptrwm_has_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "ptrwm_set_kernel_form": (C.c_int32, [C.c_int32]),
+    "ptrwm_set_stream_mode": (C.c_int32, [C.c_int32]),
+    "ptrwm_has_stream_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    "ptrwm_last_launch_kind": (C.c_int32, []),
     "ptrwm_has_quad_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "ptrwm_has_thread_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "ptrwm_auto_form": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
@@ -170,6 +176,9 @@ def load_library(path: Optional[str] = None):
     form = os.environ.get("PTRWM_KERNEL_FORM")  # tuning aid: auto | thread | quad (results are identical)
     if form:
         lib.ptrwm_set_kernel_form({"auto": FORM_AUTO, "thread": FORM_THREAD, "quad": FORM_QUAD}[form.lower()])
+    smode = os.environ.get("PTRWM_STREAM")  # tuning aid: auto | off | on (results are identical)
+    if smode:
+        lib.ptrwm_set_stream_mode({"auto": STREAM_AUTO, "off": STREAM_OFF, "on": STREAM_ON}[smode.lower()])
     if path is None:
         _lib = lib
     return lib
@@ -302,6 +311,43 @@ def set_kernel_form(form: int) -> int:
     if prev < 0:
         raise PTRWMError(prev, "ptrwm_set_kernel_form")
     return prev
+
+
+LAUNCH_THREAD, LAUNCH_QUAD, LAUNCH_STREAM = 1, 2, 3
+
+
+def last_launch_kind() -> int:
+    """Which kernel this thread's most recent ptrwm_run enqueued (LAUNCH_THREAD / LAUNCH_QUAD / LAUNCH_STREAM)."""
+    return load_library().ptrwm_last_launch_kind()
+
+
+def has_stream_variant(target_kind: int, proposal_kind: int, dim: int) -> bool:
+    """Does the one-thread-per-replica kernel of this shape have a streaming twin for short launches?"""
+    return bool(load_library().ptrwm_has_stream_variant(target_kind, proposal_kind, dim))
+
+
+def set_stream_mode(mode: int) -> int:
+    """When ptrwm_run takes the streaming form of the step kernel for short launches (STREAM_AUTO / STREAM_OFF /
+    STREAM_ON); returns the previous setting.  The forms give the same bits: this changes speed only."""
+    prev = load_library().ptrwm_set_stream_mode(mode)
+    if prev < 0:
+        raise PTRWMError(prev, "ptrwm_set_stream_mode")
+    return prev
+
+
+class stream_mode:
+    """Context manager around set_stream_mode."""
+
+    def __init__(self, mode: int):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = set_stream_mode(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_stream_mode(self.prev)
+        return False
 
 
 class kernel_form:

@@ -424,6 +424,94 @@ def test_launch_split_and_resume_are_invisible(device):
     assert np.allclose(long_run["sq_jump"], a2["sq_jump"] + b2["sq_jump"], rtol=1e-12)
 
 
+# (target, proposal, temperatures, ladders, proposal arguments, does ptrwm_run's streaming form serve this shape?)
+STREAM_CASES = [
+    ("rc15_d30", "Normal", 32, 2 * 37, dict(base_variance_scalar=2.38**2 / 30), True),   # BASELINE configs[2]'s shape
+    ("even_d30", "Laplace", 32, 2 * 20, dict(base_variance_vector=np.full(30, 0.02)), True),
+    ("tm_d50", "UniformRadius", 64, 23, dict(base_radius=2.5), True),                    # one ladder per wavefront
+    ("tm15_d30", "UniformRadius", 8, 8 * 5, dict(base_radius=2.5), True),
+    ("rc15_d30", "Normal", 1, 64 * 5, dict(base_variance_scalar=2.38**2 / 30), True),    # plain RWM: 64 chains per wavefront
+    ("rc15_d30", "Normal", 5, 12 * 7, dict(base_variance_scalar=2.38**2 / 30), True),    # 5 does not divide 64: idle lanes
+    ("full_d10", "Normal", 16, 4 * 9, dict(base_variance_scalar=0.02), True),
+    ("beta_d5", "UniformRadius", 4, 16 * 6, dict(base_radius=0.3), True),
+    ("gamma_d5", "Laplace", 3, 21 * 4, dict(base_variance_vector=np.full(5, 1.0)), False),  # 63 live lanes: no whole 16-byte pairs
+    ("rc15_d30", "Normal", 32, 2 * 37 + 1, dict(base_variance_scalar=2.38**2 / 30), False),  # a ragged last group
+    ("hyb_3_5", "Normal", 4, 16 * 3, dict(base_variance_scalar=0.03), False),             # dim 11: no kernel with dim compiled in
+]
+
+
+@pytest.mark.parametrize("tkey,pkind,T,Cn,pkw,streams", STREAM_CASES,
+                         ids=[f"{c[0]}-{c[1]}-T{c[2]}-C{c[3]}" for c in STREAM_CASES])
+def test_streaming_form_never_changes_a_result(device, tkey, pkind, T, Cn, pkw, streams):
+    """Short launches of large batches run a streaming form of the step kernel (kernel.h STREAM: persistent wavefronts,
+    the next group's state arriving by LDS-DMA while the current one is stepped; capi.hip picks it by launch length and
+    batch size).  Same Philox words, same arithmetic, same canonical order: launches of 1, 2 and 3 steps chained over two
+    and a half swap periods give, launch by launch, the bits of the classic kernel - states, log-densities, acceptance
+    and swap counts, last-swap ordinals and the fp64 squared-jump sums - and those of ONE classic launch over the whole
+    horizon.  Shapes the streaming form does not serve (ragged last group, no whole 16-byte vectors per group, no kernel
+    with dim compiled in) silently take the classic kernel under STREAM_ON."""
+    spec = H.target_spec(tkey)
+    beta = (0.05 ** (np.arange(T) / max(1, T - 1))).astype(np.float32)
+    prop = H.proposal_spec(pkind, spec.dim, beta, **pkw)
+    st0, lp0 = start_state(spec, Cn, T, np.random.default_rng(T))
+    kw = dict(beta=beta, burn_in=4, swap_every=5, seed=91, chain_offset=3)
+    keys = ("state", "logp", "n_accept", "sq_jump", "swap_accept", "last_swap_ordinal")
+    assert bool(E.has_stream_variant(spec.kind, prop.kind, spec.dim)) == (tkey != "hyb_3_5")
+    with E.kernel_form(E.FORM_THREAD):
+        for n in (1, 2, 3):
+            launches = 26 // n
+            st_c, lp_c, st_s, lp_s = st0, lp0, st0, lp0
+            tot = {k: 0 for k in keys[2:]}
+            for i in range(launches):
+                with E.stream_mode(E.STREAM_OFF):
+                    c = gpu_run(spec, prop, device, state=st_c, logp=lp_c, step0=i * n, n_steps=n, **kw)
+                    assert E.last_launch_kind() == E.LAUNCH_THREAD
+                with E.stream_mode(E.STREAM_ON):
+                    s = gpu_run(spec, prop, device, state=st_s, logp=lp_s, step0=i * n, n_steps=n, **kw)
+                    assert E.last_launch_kind() == (E.LAUNCH_STREAM if streams else E.LAUNCH_THREAD)
+                for k in keys:
+                    assert np.array_equal(c[k], s[k]), (k, n, i)
+                st_c, lp_c, st_s, lp_s = c["state"], c["logp"], s["state"], s["logp"]
+                for k in ("n_accept", "swap_accept"):
+                    tot[k] = tot[k] + s[k]
+                tot["last_swap_ordinal"] = np.maximum(tot["last_swap_ordinal"], s["last_swap_ordinal"])
+            with E.stream_mode(E.STREAM_OFF):
+                one = gpu_run(spec, prop, device, state=st0, logp=lp0, step0=0, n_steps=launches * n, **kw)
+            assert np.array_equal(one["state"], st_s) and np.array_equal(one["logp"], lp_s)
+            for k in ("n_accept", "swap_accept", "last_swap_ordinal"):
+                assert np.array_equal(one[k], tot[k]), (k, n)
+            assert one["n_accept"].sum() > 0 and (T == 1 or one["swap_accept"].sum() > 0)
+
+
+def test_streaming_form_accumulates_statistics_in_place(device):
+    """The streaming form reads the squared-jump sums of the next group ahead of time and writes old + delta back; the
+    integer statistics are added by atomics: non-zero starting values are carried exactly as the classic kernel's
+    read-modify-write carries them (the drop-in classes accumulate over many launches)."""
+    spec = H.target_spec("rc15_d30")
+    T, Cn = 32, 2 * 40
+    beta = (0.01 ** (np.arange(T) / (T - 1))).astype(np.float32)
+    prop = H.proposal_spec("Normal", 30, beta, base_variance_scalar=2.38**2 / 30)
+    st0, lp0 = start_state(spec, Cn, T, np.random.default_rng(3))
+    out = {}
+    for mode in (E.STREAM_OFF, E.STREAM_ON):
+        st, lp = dev_t(st0, device), dev_t(lp0, device)
+        stats = dict(n_accept=torch.full((Cn, T), 7, dtype=torch.int64, device=device),
+                     sq_jump=torch.full((Cn, T), 0.1, dtype=torch.float64, device=device),
+                     swap_accept=torch.full((Cn, T), 5, dtype=torch.int64, device=device),
+                     last_swap_ordinal=torch.full((Cn, T), 40, dtype=torch.int64, device=device))
+        plan = E.RunPlan(spec.engine(device), prop.engine(device), state=st, logp=lp, beta=dev_t(beta, device), burn_in=0,
+                         swap_every=3, seed=12, **stats)
+        with E.kernel_form(E.FORM_THREAD), E.stream_mode(mode):
+            for i in range(12):
+                plan.launch(i, 1)
+        torch.cuda.synchronize()
+        out[mode] = {k: v.cpu().numpy() for k, v in stats.items()}
+        out[mode]["state"] = st.cpu().numpy()
+    for k in out[E.STREAM_OFF]:
+        assert np.array_equal(out[E.STREAM_OFF][k], out[E.STREAM_ON][k]), k
+    assert (out[E.STREAM_ON]["sq_jump"] > 0.1).any() and (out[E.STREAM_ON]["last_swap_ordinal"] > 40).any()
+
+
 def test_chain_offset_makes_sharding_invisible(device):
     """Chains [0, 2n) in one call == chains [0, n) and [n, 2n) in two calls with chain_offset (multi-GPU rule)."""
     spec = H.target_spec("even_d30")

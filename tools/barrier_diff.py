@@ -27,9 +27,9 @@ CASES = [
      "lane-split HybridRosenbrock W=28 run-time dim + Laplace, production"),
     ("three_mixture", SCHED, "ptrwm_step_kernelINS_12ThreeMixtureILi64EEENS_21UniformRadiusProposalILi64EEELi64ELb0ELb1EEE",
      "thread form ThreeMixture width 64 + UniformRadius, FIXTURE variant (most spilled SGPRs of the thread form)"),
-    ("three_mixture1", SCHED, "ptrwm_step_kernelINS_13ThreeMixture1ILi50EEENS_21UniformRadiusProposalILi50EEELi50ELb1ELb0EEE",
+    ("three_mixture1", SCHED, "ptrwm_step_kernelINS_13ThreeMixture1ILi50EEENS_21UniformRadiusProposalILi50EEELi50ELb1ELb0ELb0EEE",
      "thread form ThreeMixture1 dim 50 + UniformRadius, production (BASELINE configs[4])"),
-    ("rough_carpet2", SCHED, "ptrwm_step_kernelINS_12RoughCarpetTILi30ELb1EEENS_14NormalProposalILi30EEELi30ELb1ELb0EEE",
+    ("rough_carpet2", SCHED, "ptrwm_step_kernelINS_12RoughCarpetTILi30ELb1EEENS_14NormalProposalILi30EEELi30ELb1ELb0ELb0EEE",
      "thread form RoughCarpet2 dim 30 + Normal, production (BASELINE configs[2], the headline)"),
 ]
 

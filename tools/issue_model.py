@@ -28,7 +28,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCHED = "-mllvm -enable-post-misched=0 -mllvm -amdgpu-sched-strategy=max-ilp -fno-slp-vectorize".split()
-HEADLINE = "ptrwm_step_kernelINS_12RoughCarpetTILi30ELb1EEENS_14NormalProposalILi30EEELi30ELb1ELb0EEE"
+HEADLINE = "ptrwm_step_kernelINS_12RoughCarpetTILi30ELb1EEENS_14NormalProposalILi30EEELi30ELb1ELb0ELb0EEE"
 
 # opcode (as printed, VOP suffixes stripped) -> the measured opcode whose cost it shares
 ALIAS = {

@@ -27,6 +27,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 PROD_SGPR_SPILL_CEILING = 96  # ratchet: 163 when introduced in round 3 (HybridRosenbrock<64> + UniformRadius thread form, now 34); 96 at the end of round 3 = the largest production kernel (a run-time-dim lane-split W = 28 kernel, 94) + the +-2 the count moves by between builds of unrelated changes; lower it when that kernel improves, never raise it
+STREAM_SGPR_SPILL_CEILING = 128  # the streaming twins (round 4; kernel.h STREAM): their own ratchet - the loop over groups keeps a dozen more scalars alive across the step than the classic kernel's single pass (worst when introduced: Hypercube<50> + UniformRadius, whose verdict is a chain of 64-bit lane masks)
 COLD_SCRATCH_BYTES = 64  # see the scratch rule in main()
 FIELDS = ("agpr_count", "vgpr_count", "vgpr_spill_count", "sgpr_count", "sgpr_spill_count", "private_segment_fixed_size",
           "group_segment_fixed_size")
@@ -89,19 +90,22 @@ def main():
         for name, m in found:
             n += 1
             is_step = "step_kernel" in name
-            # production = FULL false: ptrwm_step_kernel<Target, Proposal, DP, EXACT, FULL>,
+            # production = FULL false: ptrwm_step_kernel<Target, Proposal, DP, EXACT, FULL, STREAM>,
             # ptrwm_quad_step_kernel<Target, Proposal, W, DEXACT, MAXT, FULL, F64>
             if "quad_step_kernel" in name:
                 production = re.search(r"ELb0ELb[01]EEEvNS_5KArgsE$", name) is not None
             else:
-                production = is_step and re.search(r"ELb[01]ELb0EEEvNS_5KArgsE$", name) is not None
+                production = is_step and re.search(r"ELb[01]ELb0ELb[01]EEEvNS_5KArgsE$", name) is not None
             n_step += is_step
-            if production and m["sgpr_spill_count"] > worst_spill[0]:
+            if production and m["sgpr_spill_count"] > worst_spill[0] and not (
+                    is_step and "quad_step_kernel" not in name and re.search(r"ELb0ELb1EEEvNS_5KArgsE$", name)):
                 worst_spill = (m["sgpr_spill_count"], f"{base}: {short(name)}")
+            streaming = is_step and re.search(r"ELb0ELb1EEEvNS_5KArgsE$", name) is not None and "quad_step_kernel" not in name
+            ceiling = STREAM_SGPR_SPILL_CEILING if streaming else PROD_SGPR_SPILL_CEILING
             if check:
-                if production and m["sgpr_spill_count"] > PROD_SGPR_SPILL_CEILING:
+                if production and m["sgpr_spill_count"] > ceiling:
                     bad.append(f"{base}: production kernel {short(name)} spills {m['sgpr_spill_count']} SGPRs "
-                               f"(ceiling {PROD_SGPR_SPILL_CEILING})")
+                               f"(ceiling {ceiling})")
                 if m["vgpr_count"] > 256 or m["agpr_count"] > 0:
                     bad.append(f"{base}: {short(name)} needs vgpr_count {m['vgpr_count']}, agpr_count {m['agpr_count']} "
                                "(limit 256 / 0): the register regime hipcc miscompiled twice")
