@@ -231,11 +231,28 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
     if distributed:
         t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    launch_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kernel_ms = sum(launch_ms) / len(launch_ms)
+    # Per-rank record for the N > 1 line (gathered below): which physical device each rank ran on and its own launch times,
+    # so that a straggler GPU - or two ranks on one device - shows in the line itself
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_rank": local_rank, "device_index": local_dev, "device_name": props.name,
+          "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1) & 0xff,
+                                     getattr(props, "pci_device_id", -1) & 0xff),
+          "uuid": str(getattr(props, "uuid", "")), "kernel_ms_min": launch_ms[0], "kernel_ms_median": launch_ms[len(launch_ms) // 2],
+          "kernel_ms_max": launch_ms[-1], "kernel_ms_mean": kernel_ms, "wall_s": local_elapsed}
+    ranks = [me]
+    if distributed:
+        ranks = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks, me)
+    distinct = len({(r["uuid"], r["pci"]) for r in ranks})
+    if distributed and backend == "nccl" and distinct != len(ranks):
+        raise SystemExit(f"bench.py: {len(ranks)} ranks but only {distinct} distinct devices: {[(r['rank'], r['pci']) for r in ranks]}")
 
     def units_per_launch_fn(inner):
         return C * T * inner
@@ -304,26 +321,46 @@ def main():
         # ONE Metropolis step per launch (the north star's literal formulation): every launch reads and writes the whole
         # state, log-densities and the four statistics arrays once - HBM streaming is the bound.  Bytes are the arrays'
         # sizes (the PMC passes of `--inner 1` in profiles/traffic.json agree); one HIP event pair per launch.
+        import ptrwm_hip as P
+
         n1 = 300
-        for _ in range(20):
-            run.advance(1)
-        ev1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n1)]
-        torch.cuda.synchronize()
-        for a, b in ev1:
-            a.record()
-            run.advance(1)
-            b.record()
-        torch.cuda.synchronize()
-        ms1 = sorted(a.elapsed_time(b) for a, b in ev1)
+
+        def one_step_launches(mode):
+            with P.stream_mode(mode):
+                for _ in range(20):
+                    run.advance(1)
+                kind = P.last_launch_kind()
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n1)]
+                torch.cuda.synchronize()
+                for a, b in evs:
+                    a.record()
+                    run.advance(1)
+                    b.record()
+                torch.cuda.synchronize()
+            return sorted(a.elapsed_time(b) for a, b in evs), kind
+
+        # what ptrwm_run picks by itself (AUTO: the streaming form of the kernel for this shape) and, for the record, the
+        # classic kernel pinned, in the same process on the same state
+        ms1, kind1 = one_step_launches(P.STREAM_AUTO)
+        ms1_classic, _ = one_step_launches(P.STREAM_OFF)
         ms1_mean = sum(ms1) / n1
         reps_ct = C * T
         # bytes a launch really touches: state and log p read and written, the acceptance counts and the squared-jump sums
         # read-modify-written (some replica of nearly every cache line accepts), the swap counts and last-swap ordinals only
         # in the one launch in swap_every that has a swap event (the kernel leaves zero deltas alone)
         bytes1 = 2 * (reps_ct * dim * 4 + reps_ct * 4 + 2 * reps_ct * 8) + 2 * (2 * reps_ct * 8) / args.swap_every
-        inner1 = {"bound": "hbm", "bytes_per_launch": bytes1, "kernel_ms_mean": ms1_mean, "kernel_ms_median": ms1[n1 // 2],
-                  "launches": n1, "achieved": bytes1 / (ms1_mean * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                  "frac": bytes1 / (ms1_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        alg1 = (8 * dim + 24) * reps_ct  # algorithmic bytes of one Metropolis step over the batch
+        inner1 = {"bound": "hbm", "algorithmic_bytes_per_launch": alg1, "bytes_per_launch": bytes1, "kernel_ms_mean": ms1_mean,
+                  "kernel_ms_median": ms1[n1 // 2], "launches": n1,
+                  "kernel": {P.LAUNCH_THREAD: "classic", P.LAUNCH_QUAD: "lane-split", P.LAUNCH_STREAM: "streaming"}.get(kind1),
+                  # frac: by the SURVEY 8(d) accounting ((8 dim + 24) B per chain-step), the figure the north star's 0.60 is
+                  # stated in; achieved_touched / frac_touched: by the bytes the kernel really touches (int64 / fp64 statistics)
+                  "achieved": alg1 / (ms1_mean * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                  "frac": alg1 / (ms1_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                  "achieved_touched": bytes1 / (ms1_mean * 1e-3) / 1e9,
+                  "frac_touched": bytes1 / (ms1_mean * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                  "classic_kernel_pinned": {"kernel_ms_mean": sum(ms1_classic) / n1, "kernel_ms_median": ms1_classic[n1 // 2],
+                                            "frac": alg1 / (sum(ms1_classic) / n1 * 1e-3) / 1e9 / HBM_PEAK_GBPS},
                   "chain_mh_steps_per_s": reps_ct / (ms1_mean * 1e-3),
                   "note": "one MH step per launch.  bytes_per_launch = what the kernel touches: state [C,T,D] f32 and log p read "
                           "and written, accept counts (i64) and squared-jump sums (f64) read-modify-written, swap counts and "
@@ -378,8 +415,8 @@ def main():
                 inner1["profiled_kernel_ms"] = rec1.get("profiled_kernel_ms")
                 inner1["traffic_of_this_build"] = rec1.get("lib_sha256") == lib_sha
                 if inner1["traffic_of_this_build"] and inner1["traffic"]:
-                    inner1["achieved"] = inner1["traffic"] / (inner1["kernel_ms_mean"] * 1e-3) / 1e9
-                    inner1["frac"] = inner1["achieved"] / HBM_PEAK_GBPS
+                    inner1["achieved_counters"] = inner1["traffic"] / (inner1["kernel_ms_mean"] * 1e-3) / 1e9
+                    inner1["frac_counters"] = inner1["achieved_counters"] / HBM_PEAK_GBPS
         clock_ghz = rec.get("shader_clock_ghz", 2.4)
         valu_peak = 1024 * clock_ghz * 1e9 / 2  # 1024 SIMDs, one wave64 VALU instruction per 2 cycles each
         if "valu_insts_per_launch" in rec:
@@ -399,16 +436,31 @@ def main():
                     "traffic": traffic, "note_counters": f"no PMC record {key!r} in profiles/traffic.json"}
         # cost-weighted issue fraction (tools/issue_model.py: opcode histogram of one Metropolis step x measured per-opcode
         # issue cost, over the SIMD time a wave-step takes): how busy the VALU pipe is for THIS instruction mix
-        imf = os.path.join(ROOT, "profiles", "r03_issue_model.json")
-        if wl == "cfg3" and os.path.exists(imf):
+        # The ceiling of THIS instruction mix (tools/issue_model.py on profiles/r04_issue_costs.json: per-opcode issue cost
+        # in cycles of the clock measured inside each microbenchmark launch, at saturated issue; an SGPR source operand
+        # halves a full-rate opcode's rate): only 47 % of the step's VALU instructions are full-rate, so the nominal
+        # 2-cycle peak is not reachable by this kernel whatever its schedule.  peak_measured_mix = the rate at which a SIMD
+        # issues this mix when every instruction costs what it costs alone; frac_of_measured_mix = achieved over that.
+        imf = os.path.join(ROOT, "profiles", "r04_issue_model.json")
+        if wl == "cfg3" and os.path.exists(imf) and roof.get("achieved"):
             with open(imf) as f:
                 im = json.load(f)
-            roof["issue_cost_weighted"] = {
-                "frac": im.get("issue_cost_weighted"), "sum_of_standalone_costs_over_measured": im.get("sum_of_standalone_costs_over_measured"),
-                "busy_ns_per_wave_step": im.get("busy_ns_per_wave_step_in_context") or im.get("busy_ns_per_wave_step"),
-                "ns_per_wave_step": im.get("ns_per_wave_step"), "valu_on_step_path": im.get("valu_on_path"),
-                "pmc_check": im.get("pmc_check"), "source": "profiles/r03_issue_model.txt (tools/issue_model.py, tools/issue_cost.hip)",
-                "model_of_this_build": im.get("lib_sha256") == lib_sha}
+            per_inst = im.get("floor_cycles_per_valu_instruction")
+            if per_inst:
+                peak_mix = 1024 * clock_ghz / per_inst  # Gwave-instr/s
+                roof["peak_measured_mix"] = peak_mix
+                roof["frac_of_measured_mix"] = roof["achieved"] / peak_mix
+                roof["measured_mix"] = {
+                    "floor_cycles_per_valu_instruction": per_inst, "class_counts": im.get("class_counts"),
+                    "floor_cycles_per_wave_step": im.get("floor_cycles_per_wave_step"), "valu_on_step_path": im.get("valu_on_path"),
+                    "pmc_check": im.get("pmc_check"), "model_of_this_build": im.get("lib_sha256") == lib_sha,
+                    "source": "profiles/r04_issue_model.txt (tools/issue_model.py), profiles/r04_issue_costs.json "
+                              "(tools/issue_cost.hip), profiles/r04_residency.json (tools/residency_probe.hip)",
+                    "note": "frac (nominal) prices every VALU instruction at 2 cycles; this kernel's mix costs "
+                            f"{per_inst:.2f} cycles per instruction when each opcode is priced at its own saturated issue "
+                            "cost.  A fraction slightly above one is within the additivity of such costs (measured "
+                            "mixes: 0.96-1.12 of the sum of their parts): the kernel is AT the issue wall of its mix; "
+                            "only a different instruction mix makes it faster."}
         roof.update({
             "kernel": rec.get("kernel") or f"fused step kernel <{type(target).__name__}, {alg.proposal_dist.get_name()}, dim {dim}, "
                                            "production>, form chosen by the C ABI",
@@ -425,8 +477,10 @@ def main():
             "hbm_stream_inner1": inner1,
         })
         if inner1 is not None and copy_gbps:
-            # the same box's plain device-to-device copy (torch's copy_ of 1 GiB) as a second denominator
-            inner1["frac_of_measured_copy"] = inner1["achieved"] / copy_gbps
+            # the same box's plain device-to-device copy (torch's copy_ of 1 GiB) as a second denominator: the
+            # bytes really moved against the bytes a copy moves in the same time
+            inner1["frac_of_measured_copy"] = inner1["achieved_touched"] / copy_gbps
+            inner1["frac_of_measured_copy_algorithmic"] = inner1["achieved"] / copy_gbps
         out = {
             "metric": "chain-MH-steps/sec", "value": value, "unit": "chain-MH-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -437,7 +491,10 @@ def main():
                 "swap_every": args.swap_every, "swap_mode": "exchange", "swap_order": args.swap_order,
                 "rng": "Philox4x32-10 in-kernel", "sharding": f"{world} x {C} independent ladders, no data-path collective",
                 "collective_backend": (backend if distributed else None),
+                "world_size": (dist.get_world_size() if distributed else 1),
             },
+            # one entry per rank: its device and its own launch times (value uses the MAX wall clock over ranks)
+            "ranks": ranks, "distinct_devices": distinct,
             "roofline": roof,
             "summary": {
                 "acceptance_rate_cold": float(summary["acceptance_rate"][0]),

@@ -156,13 +156,14 @@ int32_t ptrwm_has_thread_variant(int32_t target_kind, int32_t proposal_kind, int
 int32_t ptrwm_auto_form(int32_t target_kind, int32_t proposal_kind, int32_t dim, int32_t n_temps, int64_t n_chains);
 
 /* ---- short launches ------------------------------------------------------
- * A launch of a few steps over a large batch (the reference's step()-at-a-time loops, rwm_gpu_optimized.py:456-457,
- * pt_rwm_gpu_optimized.py:736-737) is HBM-bound; for it ptrwm_run has a STREAMING form of the one-thread-per-replica
- * kernel: persistent wavefronts that walk the batch with the next group's state already in flight while the current one
- * is stepped.  Same Philox words and arithmetic: the same bits as the classic kernel.  AUTO takes it for launches of
- * <= 16 steps with at least two groups per resident wavefront, where the variant has a streaming twin (dims compiled
- * in, n_temps <= 64) and the batch's layout allows whole aligned 16-byte vectors per group; OFF never; ON wherever twin
- * and layout allow (tests, tuning).  Process-wide; returns the previous value, or PTRWM_E_ARG. */
+ * A launch of one step over a large batch (the reference's step()-at-a-time loops, rwm_gpu_optimized.py:456-457,
+ * pt_rwm_gpu_optimized.py:736-737) is bound by memory traffic; for it ptrwm_run has a STREAMING form of the
+ * one-thread-per-replica kernel: persistent wavefronts that walk the batch with the next group's state already in flight
+ * while the current one is stepped and the previous one's results drain.  Same Philox words and arithmetic: the same bits
+ * as the classic kernel.  AUTO takes it for one-step launches whose arrays total about the size of the Infinity Cache
+ * (192-448 MiB: where it measured faster, csrc/capi.hip), where the variant has a streaming twin (dim compiled in,
+ * n_temps <= 64) and the batch's layout allows whole aligned 16-byte vectors per group; OFF never; ON wherever twin and
+ * layout allow (tests, tuning).  Process-wide; returns the previous value, or PTRWM_E_ARG. */
 enum {
   PTRWM_STREAM_AUTO = 0,
   PTRWM_STREAM_OFF = 1,

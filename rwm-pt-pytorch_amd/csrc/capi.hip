@@ -103,21 +103,27 @@ static int g_kernel_form = PTRWM_FORM_AUTO;  // read / written with __atomic bui
 static int g_stream_mode = PTRWM_STREAM_AUTO;  // likewise (ptrwm_set_stream_mode)
 
 // ---- short launches: the streaming form of the one-thread-per-replica kernel (kernel.h STREAM) ---------------------------
-// A launch of a few Metropolis steps over a large batch - the reference's step()-at-a-time loops
-// (rwm_gpu_optimized.py:456-457, pt_rwm_gpu_optimized.py:736-737), split steps, the harness's benchmark_performance - is
-// bound by HBM, not by instruction issue: the state is read, stepped once and written back.  The classic kernel gives every
-// wave ONE group: load, compute, store, exit - the three phases of a wave do not overlap and a SIMD's resident waves run
+// A launch of ONE Metropolis step over a large batch - the reference's step()-at-a-time loops
+// (rwm_gpu_optimized.py:456-457, pt_rwm_gpu_optimized.py:736-737), the harness's benchmark_performance - is bound by
+// memory traffic, not by instruction issue: the state is read, stepped once and written back.  The classic kernel gives
+// every wave ONE group: load, compute, store, exit - the phases of a wave do not overlap and a SIMD's resident waves run
 // them nearly in lock-step.  The streaming form keeps as many waves as the device holds resident and lets each walk many
-// groups with the next group's state already in flight.  Same Philox words, same arithmetic, same canonical order:
-// bit-identical to the classic kernel (tests: test_launch_split_and_resume_are_invisible).  AUTO takes it when
-//   - the launch is short (<= kStreamMaxSteps steps: beyond that the step loop dominates and the classic kernel's extra
-//     resident wave per SIMD is worth more than the overlap),
-//   - there is something to stream (>= kStreamMinRounds groups per resident wave), and
-//   - the layout allows whole aligned 16-byte vectors per group (every group full: n_chains a multiple of the ladders per
-//     wave; cpw * n_temps * dim a multiple of 4 and cpw * n_temps even; state and sq_jump 16-byte aligned) - otherwise the
-//     classic kernel's general staging.
-constexpr int kStreamMaxSteps = 16;
-constexpr int kStreamMinRounds = 2;
+// groups with the next group's state already in flight (LDS-DMA) and the previous group's stores still draining.  Same
+// Philox words, same arithmetic, same canonical order: bit-identical to the classic kernel
+// (tests/test_gpu_engine_parity.py test_streaming_form_*).
+// Where it pays (profiles/r04_stream_variants.txt, BASELINE configs[2]'s shape over batch sizes, four boxes): two slabs of
+// rows per wave in LDS leave room for half the classic kernel's waves, so it wins where overlap is worth more than
+// residency - launches of one step whose arrays total about the size of the 256 MiB Infinity Cache (+12-13 % at
+// 65 536 ladders x 32 x dim 30, 280 MiB: reads partly served on-die, the classic kernel's lock-step the bottleneck); it
+// ties (+-2 %) on batches that fit the cache and trails by 1-6 % where everything streams from HBM (both forms then move
+// 0.86-0.9 of what a plain copy moves); from two steps per launch on the classic kernel's residency wins.  AUTO takes it
+//   - for launches of one step (kStreamMaxSteps),
+//   - whose arrays total kStreamMinBytes..kStreamMaxBytes (0.75x .. 1.75x the Infinity Cache),
+//   - where the variant has a streaming twin (dim compiled in, n_temps <= 64) and the layout allows whole aligned 16-byte
+//     vectors per group (every group full: n_chains a multiple of the ladders per wave; cpw * n_temps * dim a multiple of
+//     4 and cpw * n_temps even; state, sq_jump and n_accept 16-byte aligned) - otherwise the classic kernel's general staging.
+constexpr int kStreamMaxSteps = 1;
+constexpr long long kStreamMinBytes = 192ll << 20, kStreamMaxBytes = 448ll << 20;
 
 // what the calling thread's most recent ptrwm_run launched (ptrwm_last_launch_kind: tests and the benchmark's record)
 static thread_local int t_last_launch_kind = 0;
@@ -125,7 +131,7 @@ static thread_local int t_last_launch_kind = 0;
 static bool stream_layout_ok(const ptrwm_run_args *args, int dim, int cpw) {
   return args->n_temps <= 64 && args->n_chains % cpw == 0 && ((long long)cpw * args->n_temps * dim) % 4 == 0 &&
          (cpw * args->n_temps) % 2 == 0 && (reinterpret_cast<uintptr_t>(args->state) & 15u) == 0 &&
-         (reinterpret_cast<uintptr_t>(args->sq_jump) & 15u) == 0;
+         (reinterpret_cast<uintptr_t>(args->sq_jump) & 15u) == 0 && (reinterpret_cast<uintptr_t>(args->n_accept) & 15u) == 0;
 }
 
 // SIMDs of the current device (compute units x 4), asked once per device: the form rule is stated in wavefronts per SIMD,
@@ -663,8 +669,9 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
     if (mode == PTRWM_STREAM_ON) {
       stream = true;
     } else if (mode == PTRWM_STREAM_AUTO && args->n_steps <= kStreamMaxSteps) {
-      const long long resident = device_simds() * stream_waves_per_simd(kWidths[dpi].dp);
-      stream = args->n_chains / k.chains_per_wave >= kStreamMinRounds * resident;
+      // state + log-density + the two statistics every launch touches (acceptance count, squared-jump sum)
+      const long long bytes = args->n_chains * (long long)args->n_temps * (4ll * target->dim + 20ll);
+      stream = bytes >= kStreamMinBytes && bytes <= kStreamMaxBytes;
     }
   }
 

@@ -32,10 +32,12 @@ constexpr int kWavesPerBlock = kBlockThreads / 64;
 constexpr int kLdsExtraPerThread = 6;  // s_l, s_u, landed (swap-event scratch); c3, swap count, last event (whole launch)
 // (the streaming form, STREAM below, keeps TWO slabs of rows per wave: the one its current group lives in and the one the
 // next group's state is landing in)
-// and two small landing zones for the next group's log-densities (one float per thread) and squared-jump sums (one double)
-constexpr int kLdsStreamStatPerThread = 3;  // floats per thread and landing zone
+// and two small landing zones for the next group's log-densities (one float per thread), squared-jump sums (one double) and
+// acceptance counts (one 64-bit integer)
+constexpr int kLdsStreamStatPerThread = 5;  // floats per thread and landing zone
+constexpr int kStreamSlabs = 2;
 constexpr int lds_floats_per_thread(int dp, bool stream) {
-  return (stream ? 2 * dp + 2 * kLdsStreamStatPerThread : dp) + kLdsExtraPerThread;
+  return (stream ? kStreamSlabs * (dp + kLdsStreamStatPerThread) : dp) + kLdsExtraPerThread;
 }
 constexpr unsigned step_kernel_lds_bytes(int threads, int dp, bool stream = false) {
   return (unsigned)(threads * lds_floats_per_thread(dp, stream)) * 4u;
@@ -329,7 +331,7 @@ constexpr int min_waves_per_simd(int dp) {
 // The streaming form (STREAM, below) keeps two slabs of rows per wave in LDS: fewer waves per SIMD fit (and each gets the
 // registers of that residency).
 constexpr int stream_waves_per_simd(int dp) {  // what two slabs per wave leave room for in 160 KB of LDS per CU, at most 4
-  return dp <= 10 ? 4 : (dp <= 20 ? 3 : (dp <= 30 ? 2 : 1));
+  return dp <= 10 ? 4 : (dp <= 20 ? 2 : (dp <= 30 ? 2 : 1));
 }
 
 // (the register budget it is compiled for: never that of ONE wave per SIMD - 512 registers invite AGPR copies, the regime
@@ -375,11 +377,13 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
   // wave, not only across waves.  The next group's log-densities and squared-jump sums travel the same way into two
   // small landing zones: an ordinary load to a VGPR anywhere in this loop would make the compiler drain every
   // outstanding DMA and store (vmcnt(0)) at its first use.
-  // LDS of a wave, in floats: [slab 0: 64 DP][slab 1: 64 DP][swap scratch + parked words: 6 x 64][zone 0: 3 x 64][zone 1]
+  // LDS of a wave, in floats: [slab 0: 64 DP][slab 1: 64 DP][swap scratch + parked words: 6 x 64][zone 0: 5 x 64][zone 1]
+  // (a zone: 64 log-densities, 64 squared-jump sums, 64 acceptance counts)
   typedef float pf_vec4 __attribute__((ext_vector_type(4)));
   constexpr int NV = STREAM ? (DP + 3) / 4 : 1;  // 16-byte vectors per lane and group
   constexpr int kWaveFloats = 64 * lds_floats_per_thread(DP, STREAM);
-  constexpr int kZone0 = 64 * (2 * DP + kLdsExtraPerThread), kZoneFloats = 64 * kLdsStreamStatPerThread;
+  constexpr int kExtra0 = 64 * kStreamSlabs * DP;  // streaming form: swap scratch and parked words behind the slab(s)
+  constexpr int kZone0 = kExtra0 + 64 * kLdsExtraPerThread, kZoneFloats = 64 * kLdsStreamStatPerThread;
   [[maybe_unused]] int cur = 0;  // which slab / landing zone holds the current group (streaming form; wave-uniform)
   typedef const __attribute__((address_space(1))) void *dma_src;
   typedef __attribute__((address_space(3))) void *dma_dst;
@@ -396,6 +400,11 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
     // squared-jump sums: 16 bytes = two doubles per lane (n_live is even, capi.hip)
     if (ap->sq_jump != nullptr && 2 * tid < n_live)
       __builtin_amdgcn_global_load_lds((dma_src)(ap->sq_jump + r0 + 2 * tid), (dma_dst)(uintptr_t)(zone + 64), 16, 0, 0);
+    // acceptance counts likewise: read ahead and stored back as old + delta.  (The classic kernel adds them by no-return
+    // atomics to keep a load off the end of a wave's life; here the old value is in LDS before the step begins, and plain
+    // 8-byte stores stream at several times the rate the memory-side atomics do.)
+    if (ap->n_accept != nullptr && 2 * tid < n_live)
+      __builtin_amdgcn_global_load_lds((dma_src)(ap->n_accept + r0 + 2 * tid), (dma_dst)(uintptr_t)(zone + 192), 16, 0, 0);
     const pf_vec4 *__restrict__ gv = reinterpret_cast<const pf_vec4 *>(ap->state + g * cpw * T * (long long)D0);
     float *const dst = wbase + slab * (64 * DP);
 #pragma unroll
@@ -415,7 +424,9 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
   // the DMA is a plain vmcnt(0) that never waits for a store just issued.
   [[maybe_unused]] pf_vec4 pend_o[NV];
   [[maybe_unused]] float pend_lp = 0.0f;
-  [[maybe_unused]] unsigned pend_n_acc = 0u, pend_n_swap = 0u;
+  [[maybe_unused]] unsigned pend_n_swap = 0u;
+  [[maybe_unused]] long long pend_acc = 0;
+  [[maybe_unused]] bool pend_acc_on = false;
   [[maybe_unused]] double pend_sq = 0.0;
   [[maybe_unused]] long long pend_ord = 0, pend_group = 0;
   [[maybe_unused]] bool pend_sq_on = false, pend_ord_on = false, have_pending = false;
@@ -434,7 +445,7 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
       const long long r = pend_group * n_live + tid;
       ap->logp[r] = pend_lp;
       // statistics: only where the launch has something to add (kernel epilogue below)
-      if (ap->n_accept != nullptr && pend_n_acc != 0u) count_add(&ap->n_accept[r], (long long)pend_n_acc);
+      if (pend_acc_on) ap->n_accept[r] = pend_acc;
       if (pend_sq_on) ap->sq_jump[r] = pend_sq;
       if (ap->swap_accept != nullptr && pend_n_swap != 0u) count_add(&ap->swap_accept[r], (long long)pend_n_swap);
       // (the same maximum as the classic kernel's compare-and-store, as a no-return atomic at the L2: no load)
@@ -467,7 +478,7 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
   // (streaming form: the slab of the current group; the swap scratch and the parked words sit behind BOTH slabs)
   float *const s_stage = STREAM ? s_dyn + wave * kWaveFloats + cur * (64 * DP)
                                 : s_dyn + (wide ? 0 : (int)(threadIdx.x >> 6) * (64 * (DP + kLdsExtraPerThread)));
-  [[maybe_unused]] float *const s_extra = s_dyn + wave * kWaveFloats + 2 * (64 * DP);  // streaming form only
+  [[maybe_unused]] float *const s_extra = s_dyn + wave * kWaveFloats + kExtra0;  // streaming form only
   // group-wide ordering of LDS accesses: the group is one wave (narrow) or the workgroup (wide)
   auto sync_group = [&]() {
     if (wide) {
@@ -506,11 +517,13 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
   }
   float lp;
   [[maybe_unused]] double sq_old = 0.0;
+  [[maybe_unused]] long long acc_old = 0;
   if constexpr (STREAM) {
     {
       const float *zone = s_dyn + wave * kWaveFloats + kZone0 + cur * kZoneFloats;
       lp = zone[tid];
       if (a.sq_jump != nullptr) sq_old = reinterpret_cast<const double *>(zone + 64)[tid < cpw * T ? tid : 0];
+      if (a.n_accept != nullptr) acc_old = reinterpret_cast<const long long *>(zone + 192)[tid < cpw * T ? tid : 0];
     }
     // the previous group's results leave now, and behind them the next group's DMA is issued: the other slab is free,
     // the previous group's outgoing rows were read back into pend_o before this group began
@@ -653,7 +666,7 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
       const int group_threads = wide ? ((T + 63) & ~63) : 64;
       float *const rows = STREAM ? s_dyn + wave * kWaveFloats + cur * (64 * DP)
                                  : s_dyn + (wide ? 0 : (tid_s >> 6) * (64 * (DP + kLdsExtraPerThread)));
-      float *const s_l = STREAM ? s_dyn + wave * kWaveFloats + 2 * (64 * DP) : rows + group_threads * DP;
+      float *const s_l = STREAM ? s_dyn + wave * kWaveFloats + kExtra0 : rows + group_threads * DP;
       float *const s_u = s_l + group_threads;
       int *const park = reinterpret_cast<int *>(s_l + 3 * group_threads) + slot;
       const uint32_t c3_s = (uint32_t)park[0];
@@ -774,7 +787,7 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
     const int T_o = fresh_dim<false>(T);
     const long long rep = c0_out * T_o + (T_o > 64 ? tid_o : (tid_o & 63));  // live: replica index in group == tid
     const int gt_o = T_o > 64 ? ((T_o + 63) & ~63) : 64;
-    const int *const park = reinterpret_cast<const int *>(STREAM ? s_dyn + wave * kWaveFloats + 2 * (64 * DP) + 3 * 64
+    const int *const park = reinterpret_cast<const int *>(STREAM ? s_dyn + wave * kWaveFloats + kExtra0 + 3 * 64
                                                                  : s_dyn + (T_o > 64 ? 0 : (tid_o >> 6) * (64 * (DP + kLdsExtraPerThread)))
                                                                        + gt_o * (DP + 3)) + (T_o > 64 ? tid_o : (tid_o & 63));
     const int t = park[0] & 0xff;
@@ -784,7 +797,8 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
       // handed to flush_pending (the old squared-jump sum came in with the prefetch: the same double addition as the classic
       // kernel's read-modify-write, without a load)
       pend_lp = lp;
-      pend_n_acc = n_acc;
+      pend_acc_on = ae->n_accept != nullptr && n_acc != 0u;
+      pend_acc = acc_old + (long long)n_acc;
       pend_n_swap = n_swap_acc;
       pend_sq_on = ae->sq_jump != nullptr && sq != 0.0;
       pend_sq = sq_old + sq;

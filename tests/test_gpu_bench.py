@@ -39,6 +39,13 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     # the ranks sample different ladders (global ids 65536.. on rank 1): same statistics, not the same numbers
     assert two["summary"]["acceptance_rate_cold"] == pytest.approx(one["summary"]["acceptance_rate_cold"], rel=2e-2)
     assert two["summary"]["acceptance_rate_cold"] != one["summary"]["acceptance_rate_cold"]
+    # the line diagnoses itself: one record per rank (device identity, its own launch times), the world size it saw
+    assert one["config"]["world_size"] == 1 and two["config"]["world_size"] == 2
+    assert [r["rank"] for r in two["ranks"]] == [0, 1] and len(one["ranks"]) == 1
+    for r in two["ranks"]:
+        assert r["pci"] and r["device_name"] and 0 < r["kernel_ms_min"] <= r["kernel_ms_median"] <= r["kernel_ms_max"]
+        assert r["wall_s"] > 0
+    assert two["distinct_devices"] == 1  # the rehearsal mode: both ranks on the test box's one GPU (RCCL would refuse)
 
 
 def test_bench_under_torchrun_over_rccl():
@@ -52,3 +59,6 @@ def test_bench_under_torchrun_over_rccl():
     assert out["n_gpus"] == 1 and out["config"]["collective_backend"] == "nccl"
     assert out["summary"]["replicas"] == 65536 and out["value"] > 1e9
     assert out["roofline"]["kernel_ms"] > 0 and out["ms_per_step"] >= out["roofline"]["kernel_ms"] * 0.99
+    assert out["config"]["world_size"] == 1 and out["distinct_devices"] == 1 and len(out["ranks"]) == 1
+    r0 = out["ranks"][0]
+    assert r0["rank"] == 0 and r0["pci"] and r0["kernel_ms_mean"] == pytest.approx(out["roofline"]["kernel_ms"], rel=1e-6)

@@ -16,7 +16,16 @@ without swap events (bench.py --swap-every 1073741824, profiles/r03_pmc_cfg3_nos
 
 Output: per opcode count x cost, the sum = busy SIMD time per wave-step, and its ratio to the measured time per wave-step
 (kernel time x SIMDs / (waves x steps)) = the cost-weighted issue fraction.  Opcodes without a measured cost are priced
-as v_fma_f32 and listed."""
+as v_fma_f32 and listed.
+
+Round 4 (profiles/r04_issue_costs.json: costs in CYCLES of the clock measured inside each microbenchmark launch, at eight
+waves per SIMD = saturated issue, tools/residency_probe.hip having shown what "N waves per SIMD" really is): every VALU
+instruction on the path is priced by its opcode AND by whether it reads an SGPR - on gfx950 a full-rate opcode (2.3-2.4
+cycles per wave64 instruction: add / mul / fma / xor / shifts / bitop3 on VGPRs, inline or literal constants) issues at HALF
+rate (4.1-4.2) as soon as one source is an SGPR, the same rate as the inherently half-rate opcodes (max3 / med3 / and_or /
+cndmask / cvt / mad_u64 / mul_lo / compares / lane ops / fp64); transcendentals 8.1.  The sum is the issue-time FLOOR of the
+kernel's own instruction mix; measured cycles per wave-step (kernel time x clock x SIMDs / (waves x steps)) over that
+floor says how far the kernel is from it.  `--costs` in the old (ns) format still works."""
 import argparse
 import collections
 import json
@@ -166,12 +175,107 @@ def step_path(blocks, order):
     return header, best[1], best[0][0]
 
 
+TRANS = ("v_exp_f32", "v_log_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32", "v_rcp_f32", "v_rsq_f32")
+# opcodes that issue at half rate whatever their operands (measured: tools/issue_cost.hip) and the measured key that prices them
+HALF = {"v_max3_f32": "v_max3_f32", "v_min3_f32": "v_max3_f32", "v_med3_f32": "v_med3_f32", "v_and_or_b32": "v_and_or_b32",
+        "v_cndmask_b32": "v_cndmask_b32", "v_cvt_f32_u32": "v_cvt_f32_u32", "v_cvt_f32_i32": "v_cvt_f32_u32",
+        "v_cvt_u32_f32": "v_cvt_f32_u32", "v_mad_u64_u32": "v_mad_u64_u32", "v_mul_lo_u32": "v_mul_lo_u32",
+        "v_mul_hi_u32": "v_mul_hi_u32 v,v,v", "v_cvt_f64_f32": "v_cvt_f64_f32", "v_add_f64": "v_add_f64", "v_mul_f64": "v_fma_f64",
+        "v_fma_f64": "v_fma_f64", "v_readlane_b32": "v_readlane_b32", "v_readfirstlane_b32": "v_readlane_b32",
+        "v_writelane_b32": "v_writelane_b32", "v_mov_b32_dpp": "v_mov_b32_dpp", "v_lshl_add_u32": "v_and_or_b32",
+        "v_add3_u32": "v_and_or_b32", "v_lshl_or_b32": "v_and_or_b32", "v_bfe_u32": "v_and_or_b32", "v_xad_u32": "v_and_or_b32",
+        "v_mad_u32_u24": "v_and_or_b32", "v_lshl_add_u64": "v_add_f64", "v_mbcnt_lo_u32_b32": "v_and_or_b32",
+        "v_mbcnt_hi_u32_b32": "v_and_or_b32", "v_pk_fma_f32": "v_pk_fma_f32", "v_pk_mul_f32": "v_pk_mul_f32",
+        "v_pk_add_f32": "v_pk_add_f32"}
+# full-rate opcodes: the measured key of the all-VGPR form; with an SGPR source they cost SGPR_KEY
+FULL = {"v_add_f32": "v_add_f32", "v_sub_f32": "v_add_f32", "v_subrev_f32": "v_add_f32", "v_max_f32": "v_add_f32",
+        "v_min_f32": "v_add_f32", "v_mul_f32": "v_mul_f32", "v_mul_legacy_f32": "v_mul_f32", "v_ldexp_f32": "v_mul_f32",
+        "v_fma_f32": "v_fma_f32", "v_fmac_f32": "v_fmac_f32 v,v1,v2", "v_fmamk_f32": "v_fmamk_f32", "v_fmaak_f32": "v_fmamk_f32",
+        "v_xor_b32": "v_xor_b32", "v_and_b32": "v_and_b32 v,v,v", "v_or_b32": "v_xor_b32", "v_not_b32": "v_xor_b32",
+        "v_lshrrev_b32": "v_lshrrev_b32", "v_lshlrev_b32": "v_lshrrev_b32", "v_ashrrev_i32": "v_lshrrev_b32",
+        "v_add_u32": "v_add_u32", "v_sub_u32": "v_add_u32", "v_subrev_u32": "v_add_u32", "v_add_co_u32": "v_add_u32",
+        "v_addc_co_u32": "v_add_u32", "v_mul_u32_u24": "v_add_u32", "v_bitop3_b32": "v_bitop3_b32 v,v,v1,v2 (accumulate)",
+        "v_mov_b32": "v_add_f32", "v_accvgpr_read_b32": "v_add_f32", "v_accvgpr_write_b32": "v_add_f32"}
+SGPR_KEYS = ("v_add_f32 v,s,v", "v_fma_f32 v,v,s,s", "v_xor_b32 v,s,v", "v_mul_f32 v,s,v", "v_mov_b32 v,s", "v_bitop3_b32")
+
+
+def reads_sgpr(op, args):
+    """Does this VALU instruction read an SGPR (or VCC / EXEC) as a SOURCE operand?"""
+    parts = [p.strip() for p in re.split(r",(?![^\[]*\])", args.split(" bitop3:")[0].split(" quad_perm")[0])]
+    if op.startswith("v_cmp"):
+        srcs = parts[1:] if re.match(r"^(s\[|vcc|s\d)", parts[0]) else parts
+    elif op.startswith("v_mad_u64_u32") or op.startswith("v_add_co") or op.startswith("v_addc_co"):
+        srcs = parts[2:]
+    else:
+        srcs = parts[1:]
+    return any(re.match(r"^[-|]*(s\d+|s\[|vcc|exec|ttmp|m0)", x) for x in srcs)
+
+
+def main_cycles(a, name, header, path, pen, blocks, ops, valu, salu, ok, costs, lib_sha):
+    """Round-4 pricing: cycles at saturated issue, by opcode class and operand kind (module docstring)."""
+    cyc = {k: v["cycles"] for k, v in costs.items()}
+    sgpr_cost = sum(cyc[k] for k in SGPR_KEYS) / len(SGPR_KEYS)
+    hist = collections.Counter()  # (opcode, class) -> count
+    for b in path:
+        for o, args in blocks[b]["ins"]:
+            o = strip(o)
+            if not o.startswith("v_"):
+                continue
+            if o in TRANS:
+                hist[(o, "quarter")] += 1
+            elif o in HALF or o.startswith("v_cmp"):
+                hist[(o, "half")] += 1
+            elif o in FULL:
+                hist[(o, "full+sgpr" if reads_sgpr(o, args) else "full")] += 1
+            else:
+                hist[(o, "unpriced")] += 1
+    rows, floor, by_class, unpriced = [], 0.0, collections.Counter(), []
+    for (o, cls), c in hist.most_common():
+        if cls == "quarter":
+            each = cyc.get(o, cyc["v_exp_f32"])
+        elif cls == "half":
+            each = cyc[HALF[o]] if o in HALF else cyc["v_cmp_lt_f32"]
+        elif cls == "full":
+            each = cyc[FULL[o]]
+        elif cls == "full+sgpr":
+            each = sgpr_cost
+        else:
+            each = cyc["v_max3_f32"]  # an opcode nobody measured: priced as a half-rate one, and listed
+            unpriced.append(o)
+        rows.append((o, cls, c, each))
+        floor += c * each
+        by_class[cls] += c
+    print(f"\n{'opcode':24s} {'class':10s} {'count':>6s} {'cycles':>7s} {'sum':>8s} {'share':>6s}")
+    for o, cls, c, each in rows:
+        print(f"{o:24s} {cls:10s} {c:6d} {each:7.2f} {c * each:8.1f} {c * each / floor:6.1%}")
+    n = sum(by_class.values())
+    print(f"VALU instructions on the step path: {n}: " + ", ".join(f"{k} {v} ({v / n:.0%})" for k, v in by_class.most_common())
+          + (f"; unpriced (as half rate): {sorted(set(unpriced))}" if unpriced else ""))
+    print(f"issue-time floor of this instruction mix: {floor:.0f} cycles per wave-step = {floor / n:.2f} cycles per VALU instruction "
+          f"(nominal peak: 2.00; saturated full-rate opcode measured: {cyc['v_fma_f32']:.2f})")
+    out = {"kernel": name, "path": path, "valu_on_path": valu, "salu_on_path": salu,
+           "histogram_by_class": {f"{o} [{cls}]": c for (o, cls), c in hist.items()}, "class_counts": dict(by_class),
+           "floor_cycles_per_wave_step": floor, "floor_cycles_per_valu_instruction": floor / n, "unpriced": sorted(set(unpriced)),
+           "pmc_check": {"valu_per_wave_step": a.valu_per_wave_step, "salu_per_wave_step": a.salu_per_wave_step, "ok": ok},
+           "costs": os.path.relpath(a.costs, ROOT), "waves": a.waves, "lib_sha256": lib_sha}
+    if a.ns_per_wave_step and a.clock_ghz:
+        meas = a.ns_per_wave_step * a.clock_ghz
+        print(f"measured: {a.ns_per_wave_step:.1f} ns of SIMD time per wave-step x {a.clock_ghz:.3f} GHz = {meas:.0f} cycles = "
+              f"{meas / n:.2f} per VALU instruction  ->  floor / measured = {floor / meas:.3f}; nominal-peak fraction = {2.0 * n / meas:.3f}")
+        out.update({"ns_per_wave_step": a.ns_per_wave_step, "clock_ghz": a.clock_ghz, "measured_cycles_per_wave_step": meas,
+                    "frac_of_measured_mix": floor / meas, "frac_of_nominal_peak": 2.0 * n / meas})
+    if a.json:
+        json.dump(out, open(a.json, "w"), indent=1)
+    sys.exit(0 if ok else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tu", default="rough_carpet2")
     ap.add_argument("--kernel", default=HEADLINE)
-    ap.add_argument("--costs", default=os.path.join(ROOT, "profiles", "r03_issue_costs.json"))
-    ap.add_argument("--waves", default="waves_per_simd_4")
+    ap.add_argument("--costs", default=os.path.join(ROOT, "profiles", "r04_issue_costs.json"))
+    ap.add_argument("--waves", default="waves_per_simd_8")
+    ap.add_argument("--clock-ghz", type=float, help="shader clock of the measured kernel run (GRBM_GUI_ACTIVE / 8 / kernel time)")
     ap.add_argument("--valu-per-wave-step", type=float)
     ap.add_argument("--salu-per-wave-step", type=float)
     ap.add_argument("--ns-per-wave-step", type=float, help="measured: kernel time x SIMDs / (waves x steps)")
@@ -189,6 +293,7 @@ def main():
         a.salu_per_wave_step = rec["salu_insts_per_launch"] / (waves * steps)
         a.ns_per_wave_step = rec["profiled_kernel_ms"] * 1e6 * 1024 / (waves * steps)  # 1024 SIMDs
         lib_sha = rec["lib_sha256"]
+        a.clock_ghz = a.clock_ghz or rec.get("shader_clock_ghz")
         print(f"PMC record {a.from_traffic}: {waves:.0f} waves x {steps} steps per launch, {rec['profiled_kernel_ms']:.3f} ms")
     asm = a.asm or compile_tu(a.tu, a.flags.split() if a.flags is not None else SCHED)
     name, blocks, order = kernel_blocks(asm, a.kernel)
@@ -216,6 +321,8 @@ def main():
             print(f"check against the PMC count without swap events: {what} {got} static vs {want:.1f} counted per wave-step ({rel:+.2%})")
             ok &= abs(rel) < (0.01 if what == "VALU" else 0.05)
     costs = json.load(open(a.costs))[a.waves] if os.path.exists(a.costs) else {}
+    if costs and isinstance(next(iter(costs.values())), dict):
+        return main_cycles(a, name, header, path, pen, blocks, ops, valu, salu, ok, costs, lib_sha)
     base = costs.get("v_fma_f32")
     rows, busy, unpriced = [], 0.0, []
     for o, c in ops.most_common():

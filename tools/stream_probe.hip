@@ -75,6 +75,11 @@ static void launch(KArgs k, const Bufs &b, long long step0, int n_steps, int se,
   hipLaunchKernelGGL((ptrwm_step_kernel<Tgt, Prop, DP, true, false, STREAM>), dim3(grid), dim3(kBlockThreads), lds, 0, k);
 }
 
+// reference: a plain float4 copy of the state array (read + write of the same bytes a launch moves for the state)
+__global__ void __launch_bounds__(256) copy_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
 template <class T>
 static long long diff(const T *a, const T *b, long long n) {
   std::vector<T> ha(n), hb(n);
@@ -186,13 +191,34 @@ int main(int argc, char **argv) {
     tc[r] = time_it(false, A);
     ts[r] = time_it(true, B);
   }
+  // the copy reference, same bytes as the state traffic of one launch
+  double tcopy[3];
+  {
+    const long long n4 = reps * D / 4;
+    for (int r = 0; r < 3; ++r) {
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0));
+      CK(hipEventCreate(&e1));
+      for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(copy_kernel, dim3(cus * 8), dim3(256), 0, 0, (const float4 *)A.state, (float4 *)B.state, n4);
+      CK(hipEventRecord(e0));
+      for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(copy_kernel, dim3(cus * 8), dim3(256), 0, 0, (const float4 *)A.state, (float4 *)B.state, n4);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      tcopy[r] = (double)ms / 50;
+    }
+  }
+  const double state_bytes = 2.0 * 4.0 * D * reps;
   const double alg_bytes = (8.0 * D + 24.0) * reps;
   printf("{\"chains\": %lld, \"temps\": %d, \"dim\": %d, \"n_steps\": %d, \"cus\": %d, \"wg_per_cu\": %d, \"grid_classic\": %u, "
          "\"grid_stream\": %u, \"rounds\": %lld, \"occupancy_classic\": %d, \"occupancy_stream\": %d, "
          "\"mismatch\": {\"state\": %lld, \"logp\": %lld, \"n_accept\": %lld, \"sq_jump\": %lld, \"swap_accept\": %lld, \"last_ord\": %lld}, "
          "\"accepted_total\": %lld, \"classic_ms\": [%.5f, %.5f, %.5f], \"stream_ms\": [%.5f, %.5f, %.5f], "
-         "\"classic_frac_264B\": %.4f, \"stream_frac_264B\": %.4f}\n",
+         "\"classic_frac_264B\": %.4f, \"stream_frac_264B\": %.4f, \"copy_ms\": %.5f, \"copy_TBps\": %.3f, "
+         "\"classic_state_TBps\": %.3f, \"stream_state_TBps\": %.3f}\n",
          C, T, D, n_steps, cus, wg_per_cu, grid_classic, grid_stream, rounds, occ_c, occ_s, d_state, d_lp, d_acc, d_sq, d_sw, d_lo,
-         tot_acc, tc[0], tc[1], tc[2], ts[0], ts[1], ts[2], alg_bytes / (tc[1] * 1e-3) / 8e12, alg_bytes / (ts[1] * 1e-3) / 8e12);
+         tot_acc, tc[0], tc[1], tc[2], ts[0], ts[1], ts[2], alg_bytes / (tc[1] * 1e-3) / 8e12, alg_bytes / (ts[1] * 1e-3) / 8e12, tcopy[1], state_bytes / (tcopy[1] * 1e-3) / 1e12,
+         state_bytes / (tc[1] * 1e-3) / 1e12, state_bytes / (ts[1] * 1e-3) / 1e12);
   return (d_state | d_lp | d_acc | d_sq | d_sw | d_lo) != 0;
 }
