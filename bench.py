@@ -280,6 +280,43 @@ def main():
             return {"value": a2._run.n_replicas * a2._run.n_temps * inner / (ms * 1e-3), "kernel_ms": ms,
                     "mh_steps_per_launch": inner}
 
+        # Split steps: the path a density WITHOUT a fused kernel takes (any user-defined TorchTargetDistribution, the
+        # dense-covariance Gaussian, SuperFunnel): HIP proposal / Metropolis / swap kernels around the class's own torch
+        # log_density, per step.  Dense-covariance MultivariateNormalTorch (multivariate_normal_torch.py:62-92: a [B, D] x
+        # [D, D] product per evaluation), dim 30, a full batch and the reference's own single ladder, each replayed from a
+        # captured HIP graph (16 steps per graph, algorithms/_engine_core.py) and issued step by step from Python.
+        import warnings
+
+        from target_distributions import MultivariateNormalTorch
+
+        def split_reading(n_rep, temps, steps):
+            idx = torch.arange(dim, dtype=torch.float32)
+            cov = 0.5 ** (idx[:, None] - idx[None, :]).abs()  # a dense SPD covariance
+            out = {}
+            for name, use_graph in (("graph_replay", True), ("step_by_step", False)):
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    pt = ParallelTemperingRWM_GPU_Optimized(
+                        dim, 2.38**2 / dim, MultivariateNormalTorch(dim, cov=cov, device=dev),
+                        beta_ladder=geometric_beta_ladder(temps), swap_every=args.swap_every, burn_in=0, device=dev,
+                        num_replicas=n_rep, seed=42, trace="none")
+                    pt._ensure_started()
+                pt._run.use_graph = use_graph
+                pt._run.advance(1 + 2 * pt._run.GRAPH_STEPS)  # warm-up: capture included
+                ms = timed_launches(pt._run, 3, steps) / steps  # ms per Metropolis step
+                out[name] = {"value": n_rep * temps / (ms * 1e-3), "us_per_step": ms * 1e3}
+                del pt
+            # bytes one chain-step moves through HBM, by the arrays each kernel reads and writes (an estimate: the density's
+            # intermediates are torch's): proposal kernel 8 D + 8, density 16 D + 4, Metropolis kernel 16 D + 56
+            per = 40 * dim + 68
+            g = out["graph_replay"]
+            g["bytes_per_chain_step_estimate"] = per
+            g["GBps_estimate"] = g["value"] * per / 1e9
+            g["frac_of_hbm_peak_estimate"] = g["GBps_estimate"] / HBM_PEAK_GBPS
+            out["value"] = g["value"]
+            out["graph_over_step_by_step"] = g["value"] / out["step_by_step"]["value"]
+            return out
+
         per_launch_s = kernel_ms * 1e-3
         n_rep = max(3, int(1.0 / per_launch_s) + 1)  # launches per repeat: >= 1 s
         reps = sorted(units_per_launch_fn(args.inner) / (timed_launches(run, n_rep, args.inner) * 1e-3) for _ in range(3))
@@ -311,6 +348,10 @@ def main():
                     swap_every=args.swap_every, burn_in=0, device=dev, num_replicas=131072, seed=42, trace="none",
                     proposal_distribution=UniformRadiusProposal(50, 2.4, 1.0, dev, torch.float32)),
                 max(50, args.inner // 10), n=3),
+            "split steps (density without a fused kernel): dense-covariance MVN dim 30, 65536 ladders x 32 temps":
+                split_reading(C, T, 48),
+            "split steps: dense-covariance MVN dim 30, one ladder x 8 temps (the reference's own use)":
+                split_reading(1, 8, 1600),
             "configs[2] with swap_order=even_odd": quick(
                 lambda: ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target,
                                                            beta_ladder=geometric_beta_ladder(T),

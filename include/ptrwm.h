@@ -35,9 +35,10 @@
 extern "C" {
 #endif
 
-#define PTRWM_ABI_VERSION 2
+#define PTRWM_ABI_VERSION 3
 #define PTRWM_MAX_DIM 104  /* dim-vector lives in VGPRs; widest compiled variant */
-#define PTRWM_MAX_TEMPS 256 /* one ladder lives in one wavefront (<= 64 temps) or one 256-thread workgroup */
+#define PTRWM_MAX_TEMPS 256 /* one ladder lives in one wavefront (<= 64 temps) or one workgroup; above dim 64 (lane-split
+                              kernel only, 512-thread workgroups): at most 128, longer ladders get PTRWM_E_NOVARIANT */
 
 /* ---- status codes ------------------------------------------------------ */
 enum {
@@ -154,6 +155,17 @@ int32_t ptrwm_has_thread_variant(int32_t target_kind, int32_t proposal_kind, int
 /* The form PTRWM_FORM_AUTO runs for a float-state launch of this shape on the current device (PTRWM_FORM_THREAD or
  * PTRWM_FORM_QUAD), or a negative status.  Introspection only: the forms give the same bits. */
 int32_t ptrwm_auto_form(int32_t target_kind, int32_t proposal_kind, int32_t dim, int32_t n_temps, int64_t n_chains);
+/* The same rule for a device of n_simds SIMDs (no HIP call: a pure function of its arguments and of the fitted table). */
+int32_t ptrwm_auto_form_for(int32_t target_kind, int32_t proposal_kind, int32_t dim, int32_t n_temps, int64_t n_chains,
+                            int32_t n_simds);
+/* SIMDs (compute units x 4) of the device that owns `stream` (NULL: the calling thread's current device): what the AUTO
+ * rule of ptrwm_run scales by; PTRWM_E_LAUNCH if the runtime cannot say (AUTO then keeps the thread form). */
+int32_t ptrwm_device_simds(void *stream);
+/* Identity of the build as far as kernel speed goes: sha256 over the kernel sources (tools/source_hash.py), and the hash
+ * of the sources the AUTO form table (csrc/form_table.inc) was fitted on.  Different strings: the table is stale - the
+ * forms still give the same bits, AUTO may just not pick the faster one - re-fit with tools/form_sweep.py + form_fit.py. */
+const char *ptrwm_source_hash(void);
+const char *ptrwm_form_table_source_hash(void);
 
 /* ---- short launches ------------------------------------------------------
  * A launch of one step over a large batch (the reference's step()-at-a-time loops, rwm_gpu_optimized.py:456-457,
@@ -238,6 +250,14 @@ typedef struct ptrwm_run_args {
    * reference's PT class is Gaussian only).  Always the lane-split form of the kernel; ladders of <= 128 temperatures. */
   int32_t state_f64;
   int32_t reserved0; /* must be 0 */
+  /* Split steps only (ptrwm_split_propose / ptrwm_split_accept / ptrwm_split_advance; must be NULL for ptrwm_run and
+   * ptrwm_swap_sweep): device pointer to the 0-based index of the step to perform.  When set, the kernels read the step
+   * index from device memory instead of `step0` (which is ignored), derive burn-in and swap schedule from it on the
+   * device, and ptrwm_split_accept ALWAYS enqueues the swap kernel (it returns at once when no event is due): the argument
+   * list of a step no longer depends on the step, so a sequence of split steps - the caller's density evaluation
+   * included - can be captured ONCE in a HIP graph (torch.cuda.CUDAGraph) and replayed, with ptrwm_split_advance as
+   * the last node of every step.  External randoms (ext_prop / ext_u / ext_swap_u) are not available in this mode. */
+  const int64_t *device_step;
 } ptrwm_run_args;
 
 /* Advance every (chain, temperature) replica by n_steps Metropolis steps (with
@@ -277,6 +297,8 @@ int32_t ptrwm_split_propose(const ptrwm_proposal_desc *proposal, const ptrwm_run
                             float *proposals, float *accept_u, void *stream);
 int32_t ptrwm_split_accept(const ptrwm_run_args *args, int32_t dim, float *proposals, const float *accept_u,
                            const float *logp_proposed, void *stream);
+/* *args->device_step += 1 on `stream` (one thread): the last node of a split step in device-step mode. */
+int32_t ptrwm_split_advance(const ptrwm_run_args *args, void *stream);
 
 /* out[i] = log_density(x[i, :]) for i < n; x is device [n, dim], out device [n]. */
 int32_t ptrwm_logdensity(const ptrwm_target_desc *target, const float *x, float *out, int64_t n,

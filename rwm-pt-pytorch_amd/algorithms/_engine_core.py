@@ -73,6 +73,10 @@ class EngineRun:
             self.density_fn = target_dist.log_density
             warnings.warn(f"{type(target_dist).__name__} has no fused kernel: running split steps (HIP proposal / "
                           "accept / swap kernels around its log_density, three launches per step).")
+        if self.target is not None and not (ptrwm_hip.has_thread_variant(self.target.kind, proposal.kind, dim)
+                                            or ptrwm_hip.has_quad_variant(self.target.kind, proposal.kind, dim, n_temps)):
+            raise ValueError(f"no fused kernel for dim {dim} with a ladder of {n_temps} temperatures: above dim 64 a ladder "
+                             "holds at most 128 temperatures (one 512-thread workgroup of the lane-split kernel)")
         self.proposal = proposal
         self.dim, self.n_temps, self.n_replicas = dim, n_temps, n_replicas
         self.device = device
@@ -83,6 +87,8 @@ class EngineRun:
         self.chain_offset = int(chain_offset)
         self.steps_done = 0
         self.manual_sweeps = 0  # stand-alone swap events (swap_sweep) performed so far
+        self.use_graph = True   # split steps: replay a captured HIP graph where no per-step trace is asked for
+        self._graph = None
         self.beta = torch.tensor(list(beta_ladder), device=device, dtype=torch.float32)
         if dtype not in (torch.float32, torch.float64):
             raise TypeError(f"state dtype must be torch.float32 or torch.float64, got {dtype}")
@@ -140,8 +146,76 @@ class EngineRun:
                               trace_every=trace_every, swap_event_offset=self.manual_sweeps)
         self.steps_done += n_steps
 
+    # ---- split steps through a captured HIP graph ------------------------------------------------------------
+    # A split step is four launches of this library (proposal, Metropolis rule, swap event, step counter) around the
+    # caller's density evaluation.  Issued one by one from Python they cost two ctypes calls plus the density's own torch
+    # dispatch per step - tens of microseconds of host time against a few microseconds of kernels for a small batch.  In
+    # device-step mode (include/ptrwm.h `device_step`) no argument of those launches depends on the step, so GRAPH_STEPS
+    # steps are captured ONCE with torch.cuda.CUDAGraph - the density's kernels included - and replayed.  Same kernels,
+    # same Philox words: bit-identical to the eager loop and (with the library's own density) to ptrwm_run.
+    GRAPH_STEPS = 16
+
+    def _split_step_on_device_counter(self) -> None:
+        C, T, D = self.n_replicas, self.n_temps, self.dim
+        props = self._plan.split_propose(0)
+        lp_new = self._density(props.view(-1, D)).view(C, T)
+        self._plan.split_accept(0, lp_new, swap_event_offset=self.manual_sweeps)
+        self._plan.split_advance()
+
+    def _advance_split_graph(self, n_steps: int) -> bool:
+        """n_steps split steps by graph replay; False if the density cannot be captured (the caller falls back)."""
+        if getattr(self, "_graph_failed", False):
+            return False
+        if getattr(self, "_dstep", None) is None:
+            self._dstep = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._dstep.fill_(self.steps_done)
+        self._plan.set_device_step(self._dstep)
+        try:
+            done = 0
+            key = self.manual_sweeps  # (baked into the captured swap launch)
+            if getattr(self, "_graph_key", None) != key:
+                self._graph = None
+            if self._graph is None:
+                # one step outside capture first, on a side stream (lazy initialisations of whatever the density calls
+                # must not happen while capturing); it is a real step of the run
+                cur = torch.cuda.current_stream(self.device)
+                side = torch.cuda.Stream(self.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    self._split_step_on_device_counter()
+                cur.wait_stream(side)
+                done = 1
+                if n_steps - done >= self.GRAPH_STEPS:
+                    g = torch.cuda.CUDAGraph()
+                    try:
+                        with torch.cuda.graph(g):
+                            for _ in range(self.GRAPH_STEPS):
+                                self._split_step_on_device_counter()
+                    except Exception as e:  # a density that synchronises, allocates outside the pool, ...
+                        self._graph_failed = True
+                        torch.cuda.synchronize(self.device)
+                        warnings.warn(f"split steps: the density could not be captured in a HIP graph ({type(e).__name__}: {e}); "
+                                      "running step by step")
+                        self._dstep.fill_(self.steps_done + done)
+                        for _ in range(n_steps - done):
+                            self._split_step_on_device_counter()
+                        self.steps_done += n_steps
+                        return True
+                    self._graph, self._graph_key = g, key
+            while self._graph is not None and n_steps - done >= self.GRAPH_STEPS:
+                self._graph.replay()
+                done += self.GRAPH_STEPS
+            for _ in range(n_steps - done):
+                self._split_step_on_device_counter()
+            self.steps_done += n_steps
+            return True
+        finally:
+            self._plan.set_device_step(None)
+
     def _advance_split(self, n_steps, trace, trace_logp, trace_row0, trace_every) -> None:
         """n_steps split steps; traced steps (step_counter a multiple of trace_every) are copied with torch."""
+        if trace is None and n_steps >= 2 and self.use_graph and self._advance_split_graph(n_steps):
+            return
         C, T, D = self.n_replicas, self.n_temps, self.dim
         row = trace_row0
         for _ in range(n_steps):

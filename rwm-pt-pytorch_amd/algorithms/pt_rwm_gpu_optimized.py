@@ -99,6 +99,20 @@ class ParallelTemperingRWM_GPU_Optimized(MHAlgorithm):
                 warnings.warn("No specific ladder construction method chosen. Using geometric spacing as default.")
 
         self.num_chains = len(self.beta_ladder)  # = number of temperatures, as in the reference
+        # Double states need the lane-split kernel with double state registers (ladders of <= 128 temperatures) and a target
+        # with a fused kernel (split steps carry float32 states).  What it cannot serve runs in float32 and says so - the
+        # reference's scripts pass --use_double_precision to every target (experiment_pt_GPU.py:236) and must keep running.
+        if self.dtype == torch.float64:
+            has_kernel = True
+            try:
+                self.target_dist.engine_target()
+            except (NotImplementedError, AttributeError):
+                has_kernel = False
+            if not has_kernel or self.num_chains > 128:
+                warnings.warn("dtype=torch.float64 is served by the fused kernel for ladders of <= 128 temperatures only: "
+                              + (f"{type(self.target_dist).__name__} has no fused kernel (split steps)" if not has_kernel
+                                 else f"{self.num_chains} temperatures") + "; states are kept in float32")
+                self.dtype = torch.float32
         self.num_replicas = int(num_replicas)
         self.beta_tensor = torch.tensor(self.beta_ladder, device=self.device, dtype=torch.float32)
 

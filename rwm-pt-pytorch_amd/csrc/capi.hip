@@ -134,29 +134,39 @@ static bool stream_layout_ok(const ptrwm_run_args *args, int dim, int cpw) {
          (reinterpret_cast<uintptr_t>(args->sq_jump) & 15u) == 0 && (reinterpret_cast<uintptr_t>(args->n_accept) & 15u) == 0;
 }
 
-// SIMDs of the current device (compute units x 4), asked once per device: the form rule is stated in wavefronts per SIMD,
-// so a partitioned or CU-masked device (or another CDNA part) gets the rule scaled to what it really has.
-static long long device_simds() {
+// SIMDs (compute units x 4) of the device that owns `stream` - the device the launch will run on - or, for the NULL
+// stream, of the calling thread's current device; asked once per device; 0 if the runtime cannot say.  The form rule is
+// stated in wavefronts per SIMD, so a partitioned or CU-masked device (or another CDNA part) gets the rule scaled to what
+// it really has - and where the count is unknown AUTO keeps the one-thread-per-replica form (never wrong, only a speed).
+static long long device_simds(hipStream_t stream) {
   constexpr int kMaxDevices = 64;
   static int cached[kMaxDevices];  // 0 = not asked yet (a race merely asks twice)
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 1024;
+  int dev = -1;
+  hipDevice_t owner;
+  if (stream != nullptr && hipStreamGetDevice(stream, &owner) == hipSuccess) dev = (int)owner;
+  else if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+  if (dev < 0 || dev >= kMaxDevices) return 0;
   int n = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
   if (n == 0) {
     int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
     n = 4 * cus;
     __atomic_store_n(&cached[dev], n, __ATOMIC_RELAXED);
   }
   return n;
 }
 
-// AUTO's choice for a launch of n_chains ladders where both forms exist
-static bool auto_prefers_lane_split(int dim, int n_temps, long long n_chains) {
+// AUTO's choice for a launch of n_chains ladders on a device of n_simds SIMDs where both forms exist
+static bool auto_prefers_lane_split(int dim, int n_temps, long long n_chains, long long n_simds) {
+  if (n_simds <= 0) return false;
   const long long cpw1 = n_temps > 64 ? 1 : 64 / n_temps;
   const long long waves1 = n_temps > 64 ? n_chains * ((n_temps + 63) / 64) : (n_chains + cpw1 - 1) / cpw1;
-  return lane_split_is_faster(dim, n_temps, (double)waves1 / (double)device_simds());
+  return lane_split_is_faster(dim, n_temps, (double)waves1 / (double)n_simds);
 }
+
+#ifndef PTRWM_SOURCE_HASH
+#define PTRWM_SOURCE_HASH "unknown (built without csrc/Makefile)"
+#endif
 
 
 // alt: the specialised functor of the kind - RoughCarpet2 (the host proved the third mixture term negligible,
@@ -280,6 +290,8 @@ static TParams make_tparams(const ptrwm_target_desc *t) {
   return tp;
 }
 
+__global__ void split_advance_kernel(long long *device_step) { *device_step += 1; }
+
 __global__ void philox_raw_kernel(uint32_t *__restrict__ out, long long n, uint32_t c0, uint32_t c1, uint32_t c2,
                                   uint32_t c3, uint32_t k0, uint32_t k1) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -304,14 +316,31 @@ struct SweepArgs {
   unsigned long long step;
   int n_temps, dim, swap_mode, swap_order, rng_stream, chunk;
   unsigned k0, k1;
+  // device-step mode (include/ptrwm.h device_step): the step index, whether an event is due and its number come from here
+  const long long *device_step;
+  long long burn_in, swap_every, event_offset;
 };
-constexpr int kSweepLdsFloats = 8192;
+constexpr int kSweepLdsBytes = 32768;  // at most: rows (and, in a split step, the pre-step rows) of one column chunk
 
-__global__ void __launch_bounds__(256) swap_sweep_kernel(const SweepArgs a) {
-  __shared__ float s_rows[kSweepLdsFloats];
+// state_t: float, or double for the reference's dtype=torch.float64 states (ptrwm_swap_sweep with state_f64 = 1: the
+// permutation only - the squared-jump bookkeeping belongs to split steps, which carry float states).
+// LDS is sized by the launch to what the ladder needs (rows of one column chunk, twice that in a split step): round 3's
+// fixed 32 KB left four workgroups - four wavefronts - per CU and the kernel at a tenth of the memory rate.
+template <class state_t>
+__global__ void __launch_bounds__(256) swap_sweep_kernel(SweepArgs a) {
+  if (a.device_step != nullptr) {
+    // the swap event of step *device_step, if that step has one (ptrwm_split_accept's host-side rule, on the device)
+    const long long s0 = *a.device_step, sc = s0 + 1;
+    if (!(sc > a.burn_in && sc % a.swap_every == 0)) return;  // (grid-uniform)
+    a.step = (unsigned long long)s0;
+    a.event_index = sc / a.swap_every - a.burn_in / a.swap_every - 1 + a.event_offset;
+  }
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_sweep[];
   __shared__ float s_l[256], s_u[256];
   __shared__ int s_src[256];
   const int T = a.n_temps, D = a.dim, tid = threadIdx.x, nthr = blockDim.x;
+  state_t *const s_rows = reinterpret_cast<state_t *>(s_sweep);
+  state_t *const s_prev = s_rows + T * a.chunk;  // (split steps only)
   const long long chain = blockIdx.x;
   const bool live = tid < T;
   const int t = live ? tid : 0;
@@ -331,25 +360,27 @@ __global__ void __launch_bounds__(256) swap_sweep_kernel(const SweepArgs a) {
     s_l[tid] = my_l;
     s_u[tid] = us;
   }
-  __syncthreads();
+  // the ladder's verdict on the form of its sequential sweep, from the values it enters the event with (kernel.h)
+  const bool plain = __syncthreads_and(swap_pair_plain(T, t, sub_rn(a.beta[t], a.beta[t < T - 1 ? t + 1 : t]), my_l, us) ? 1 : 0) != 0;
   int src = t;
   bool pair_acc = false;
   __shared__ int s_landed[256];
   swap_decide(T, t, 0, t, a.swap_mode, a.swap_order, (int)(a.event_index & 1), a.beta, a.beta[t], us, s_l, s_u, s_landed,
-              my_l, src, pair_acc, [] { __syncthreads(); },
-              __syncthreads_and(swap_threshold_ok(T, t, a.beta, a.beta[t], my_l) ? 1 : 0) != 0);
+              my_l, src, pair_acc, [] { __syncthreads(); }, plain);
   if (live) s_src[tid] = src;
   __syncthreads();
-  float *gs = a.state + chain * T * (long long)D;
+  state_t *gs = reinterpret_cast<state_t *>(a.state) + chain * T * (long long)D;
   const float *prev = a.prev != nullptr ? a.prev + chain * T * (long long)D : nullptr;
   // |final - prev|^2 of this thread's replica in the canonical four-range order of the fused kernel (philox.h)
   const int W = canon_width(D);
   float j2p0 = 0.0f, j2p1 = 0.0f, j2p2 = 0.0f, j2p3 = 0.0f;
   for (int c0 = 0; c0 < D; c0 += a.chunk) {
     const int w = (D - c0 < a.chunk) ? D - c0 : a.chunk;
+    const bool whole = w == D;  // one chunk holds whole rows: element i of the tile is element i of the ladder's run
     for (int i = tid; i < T * w; i += nthr) {
-      const int tt = i / w, dd = i - tt * w;
+      const int tt = whole ? 0 : i / w, dd = whole ? i : i - tt * w;
       s_rows[i] = gs[tt * D + c0 + dd];
+      if (prev != nullptr) s_prev[i] = static_cast<state_t>(prev[tt * D + c0 + dd]);
     }
     __syncthreads();
     for (int i = tid; i < T * w; i += nthr) {
@@ -358,7 +389,7 @@ __global__ void __launch_bounds__(256) swap_sweep_kernel(const SweepArgs a) {
     }
     if (live && prev != nullptr) {
       for (int dd = 0; dd < w; ++dd) {
-        const float dl = sub_rn(s_rows[src * w + dd], prev[t * D + c0 + dd]);
+        const float dl = sub_rn(static_cast<float>(s_rows[src * w + dd]), static_cast<float>(s_prev[t * w + dd]));
         const int qi = (c0 + dd) / W;
         if (qi == 0) j2p0 = fmaf(dl, dl, j2p0);
         else if (qi == 1) j2p1 = fmaf(dl, dl, j2p1);
@@ -393,33 +424,67 @@ struct SplitAcceptArgs {
   unsigned char *accept_flags;
   long long n_reps;
   int n_temps, dim, count_on, swap_due;
+  const long long *device_step;  // device-step mode: count_on / swap_due are derived from *device_step
+  long long burn_in, swap_every;
 };
 
-__global__ void __launch_bounds__(256) split_accept_kernel(const SplitAcceptArgs a) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n_reps) return;
-  const int t = (int)(i % a.n_temps);
-  const float lp = a.logp[i], lp_new = a.logp_new[i];
-  const bool acc = mh_accept(a.beta[t], lp_new, lp, a.accept_u[i]);
-  float *__restrict__ x = a.state + i * a.dim;
-  float *__restrict__ y = a.proposals + i * a.dim;
-  // squared jump in the canonical four-range order of the fused kernel (philox.h)
-  const int W = canon_width(a.dim);
-  float j2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int d1 = (q + 1) * W < a.dim ? (q + 1) * W : a.dim;
-    for (int d = q * W; d < d1; ++d) {
-      const float xo = x[d], yn = y[d];
-      const float dl = sub_rn(yn, xo);
-      j2p[q] = fmaf(dl, dl, j2p[q]);
-      if (acc) x[d] = yn;
-      y[d] = xo;
-    }
+// One wavefront per tile of 64 replicas (64-thread workgroups): the tile's rows of `state` and of `proposals` go through two
+// slabs of LDS in both directions (kernel.h stage_copy: coalesced 16-byte transfers), every lane works on its own row in
+// LDS.  (Round 3's version walked its rows in HBM, 64 cache lines per instruction: 2.6 ms per step at 65 536 x 32 x
+// dim 30 - 70 % of a split step - where moving the bytes takes 0.2.)
+__global__ void __launch_bounds__(64) split_accept_kernel(SplitAcceptArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_tiles[];
+  const int lane = (int)threadIdx.x;
+  const long long first = (long long)blockIdx.x * 64;
+  if (first >= a.n_reps) return;
+  if (a.device_step != nullptr) {
+    const long long sc = *a.device_step + 1;  // step_counter of this step
+    a.count_on = sc > a.burn_in;
+    a.swap_due = a.n_temps > 1 && a.count_on && (sc % a.swap_every == 0);
   }
-  // (the proposal's own squared jump when ptrwm_split_propose recorded one: second plane of accept_u, kernel.h)
-  const float given = a.accept_u[a.n_reps + i];
-  const float j2 = given >= 0.0f ? given : tree4_add(j2p);
+  const int D = a.dim;
+  const int n_rows = (a.n_reps - first < 64) ? (int)(a.n_reps - first) : 64;
+  float *const xs = s_tiles, *const ys = s_tiles + (64 * D + 4);
+  float *__restrict__ gx = a.state + first * D;
+  float *__restrict__ gy = a.proposals + first * D;
+  stage_copy<true>(xs, gx, n_rows * D, lane, 64);
+  stage_copy<true>(ys, gy, n_rows * D, lane, 64);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const bool live = lane < n_rows;
+  const long long i = first + (live ? lane : 0);
+  bool acc = false;
+  float lp_new = 0.0f, j2 = 0.0f;
+  if (live) {
+    const int t = (int)(i % a.n_temps);
+    const float lp = a.logp[i];
+    lp_new = a.logp_new[i];
+    acc = mh_accept(a.beta[t], lp_new, lp, a.accept_u[i]);
+    float *__restrict__ x = xs + stage_head(gx) + lane * D;
+    float *__restrict__ y = ys + stage_head(gy) + lane * D;
+    // squared jump in the canonical four-range order of the fused kernel (philox.h)
+    const int W = canon_width(D);
+    float j2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int d1 = (q + 1) * W < D ? (q + 1) * W : D;
+      for (int d = q * W; d < d1; ++d) {
+        const float xo = x[d], yn = y[d];
+        const float dl = sub_rn(yn, xo);
+        j2p[q] = fmaf(dl, dl, j2p[q]);
+        if (acc) x[d] = yn;
+        y[d] = xo;
+      }
+    }
+    // (the proposal's own squared jump when ptrwm_split_propose recorded one: second plane of accept_u, kernel.h)
+    const float given = a.accept_u[a.n_reps + i];
+    j2 = given >= 0.0f ? given : tree4_add(j2p);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  stage_copy<false>(xs, gx, n_rows * D, lane, 64);
+  stage_copy<false>(ys, gy, n_rows * D, lane, 64);
+  if (!live) return;
   if (acc) a.logp[i] = lp_new;
   if (a.accept_flags != nullptr) a.accept_flags[i] = acc ? 1 : 0;
   if (a.count_on) {
@@ -433,14 +498,15 @@ template <template <int> class Proposal>
 static hipError_t launch_split_propose(int wi, const float *state, float *proposals, float *accept_u, long long n_chains,
                                        long long chain_offset, unsigned long long step, int D, int T, const float *ts,
                                        const PParams &pp, const float *ext_raw, const float *ext_u, int n_raw,
-                                       unsigned k0, unsigned k1, hipStream_t st) {
+                                       unsigned k0, unsigned k1, const long long *dstep, hipStream_t st) {
   const long long tot = n_chains * T;
-  const dim3 grid((unsigned)((tot + kBlockThreads - 1) / kBlockThreads)), block(kBlockThreads);
+  const dim3 grid((unsigned)((tot + 63) / 64)), block(64);  // one wavefront per tile of 64 replicas (kernel.h)
+  const unsigned lds = split_tile_lds_bytes(D);
   int idx = 0;
 #define PTRWM_X_SPLIT(W, E)                                                                                       \
   if (wi == idx++)                                                                                                \
-    hipLaunchKernelGGL((ptrwm_split_propose_kernel<Proposal<W>, W>), grid, block, 0, st, state, proposals,       \
-                       accept_u, n_chains, chain_offset, step, D, T, ts, pp, ext_raw, ext_u, n_raw, k0, k1);
+    hipLaunchKernelGGL((ptrwm_split_propose_kernel<Proposal<W>, W>), grid, block, lds, st, state, proposals,     \
+                       accept_u, n_chains, chain_offset, step, D, T, ts, pp, ext_raw, ext_u, n_raw, k0, k1, dstep);
   PTRWM_WIDTHS(PTRWM_X_SPLIT)
 #undef PTRWM_X_SPLIT
   return hipGetLastError();
@@ -481,11 +547,24 @@ static int32_t launch_sweep(const ptrwm_run_args *args, int32_t dim, int64_t eve
   a.swap_mode = args->swap_mode;
   a.swap_order = args->swap_order;
   a.rng_stream = rng_stream;
-  a.chunk = kSweepLdsFloats / args->n_temps;  // >= 32 columns per pass
+  // columns per pass: whole rows where they fit the LDS budget (a split step stages the pre-step rows beside them)
+  const bool f64 = args->state_f64 == 1;
+  const int per_elem = (f64 ? 8 : 4) * (prev != nullptr ? 2 : 1);
+  int chunk = kSweepLdsBytes / (per_elem * args->n_temps);  // >= 16 columns
+  if (chunk > dim) chunk = dim;
+  a.chunk = chunk;
+  const unsigned lds = (unsigned)(chunk * args->n_temps * per_elem);
   a.k0 = (unsigned)(args->seed & 0xffffffffull);
   a.k1 = (unsigned)(args->seed >> 32);
+  a.device_step = prev != nullptr ? (const long long *)args->device_step : nullptr;  // (split steps only)
+  a.burn_in = args->burn_in;
+  a.swap_every = args->swap_every;
+  a.event_offset = args->swap_event_offset;
   const unsigned block = (unsigned)((args->n_temps + 63) / 64 * 64);
-  hipLaunchKernelGGL(swap_sweep_kernel, dim3((unsigned)args->n_chains), dim3(block), 0, stream, a);
+  if (f64)
+    hipLaunchKernelGGL(swap_sweep_kernel<double>, dim3((unsigned)args->n_chains), dim3(block), lds, stream, a);
+  else
+    hipLaunchKernelGGL(swap_sweep_kernel<float>, dim3((unsigned)args->n_chains), dim3(block), lds, stream, a);
   return hipGetLastError() == hipSuccess ? PTRWM_OK : PTRWM_E_LAUNCH;
 }
 
@@ -537,15 +616,29 @@ int32_t ptrwm_has_quad_variant(int32_t target_kind, int32_t proposal_kind, int32
   return qi >= 0 && quad_variants(target_kind, false).run[proposal_kind][qi] != nullptr ? 1 : 0;
 }
 
-int32_t ptrwm_auto_form(int32_t target_kind, int32_t proposal_kind, int32_t dim, int32_t n_temps, int64_t n_chains) {
-  if (n_temps < 1 || n_temps > PTRWM_MAX_TEMPS || n_chains < 1) return PTRWM_E_ARG;
+int32_t ptrwm_device_simds(void *stream) {
+  const long long n = device_simds((hipStream_t)stream);
+  return n > 0 ? (int32_t)n : PTRWM_E_LAUNCH;
+}
+
+int32_t ptrwm_auto_form_for(int32_t target_kind, int32_t proposal_kind, int32_t dim, int32_t n_temps, int64_t n_chains,
+                            int32_t n_simds) {
+  if (n_temps < 1 || n_temps > PTRWM_MAX_TEMPS || n_chains < 1 || n_simds < 1) return PTRWM_E_ARG;
   const bool th = ptrwm_has_thread_variant(target_kind, proposal_kind, dim) != 0;
   const bool qu = ptrwm_has_quad_variant(target_kind, proposal_kind, dim, n_temps) != 0;
   if (!th && !qu) return PTRWM_E_NOVARIANT;
   if (!th) return PTRWM_FORM_QUAD;
   if (!qu) return PTRWM_FORM_THREAD;
-  return auto_prefers_lane_split(dim, n_temps, n_chains) ? PTRWM_FORM_QUAD : PTRWM_FORM_THREAD;
+  return auto_prefers_lane_split(dim, n_temps, n_chains, n_simds) ? PTRWM_FORM_QUAD : PTRWM_FORM_THREAD;
 }
+
+int32_t ptrwm_auto_form(int32_t target_kind, int32_t proposal_kind, int32_t dim, int32_t n_temps, int64_t n_chains) {
+  const int32_t n = ptrwm_device_simds(nullptr);
+  return n < 0 ? n : ptrwm_auto_form_for(target_kind, proposal_kind, dim, n_temps, n_chains, n);
+}
+
+const char *ptrwm_source_hash(void) { return PTRWM_SOURCE_HASH; }
+const char *ptrwm_form_table_source_hash(void) { return kFormTableSourceHash; }
 
 int32_t ptrwm_has_thread_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim) {
   if (target_kind < 0 || target_kind >= PTRWM_TARGET_COUNT) return 0;
@@ -584,7 +677,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
     return PTRWM_E_ARG;
   if (args->swap_mode != PTRWM_SWAP_EXCHANGE && args->swap_mode != PTRWM_SWAP_REFERENCE_COPY) return PTRWM_E_ARG;
   if (args->swap_order != PTRWM_ORDER_SEQUENTIAL && args->swap_order != PTRWM_ORDER_EVEN_ODD) return PTRWM_E_ARG;
-  if ((args->state_f64 != 0 && args->state_f64 != 1) || args->reserved0 != 0) return PTRWM_E_ARG;
+  if ((args->state_f64 != 0 && args->state_f64 != 1) || args->reserved0 != 0 || args->device_step != nullptr) return PTRWM_E_ARG;
   if (args->n_chains == 0 || args->n_steps == 0) return PTRWM_OK;  // empty batch: nothing to touch
   if (args->state == nullptr || args->logp == nullptr || args->beta == nullptr || proposal->temp_scale == nullptr)
     return PTRWM_E_NULL;
@@ -615,7 +708,8 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
       fn = qfn;  // the only form with double state registers (null: ladder too long for a 512-thread workgroup)
       quad = true;
     } else if (qfn != nullptr && (fn == nullptr || form != PTRWM_FORM_THREAD)) {
-      quad = fn == nullptr || form == PTRWM_FORM_QUAD || auto_prefers_lane_split(target->dim, args->n_temps, args->n_chains);
+      quad = fn == nullptr || form == PTRWM_FORM_QUAD ||
+             auto_prefers_lane_split(target->dim, args->n_temps, args->n_chains, device_simds((hipStream_t)hip_stream));
       if (quad) fn = qfn;
     }
   }
@@ -725,7 +819,7 @@ int32_t ptrwm_swap_sweep(const ptrwm_run_args *args, int32_t dim, int64_t event_
                          void *stream) {
   if (args == nullptr) return PTRWM_E_NULL;
   if (args->struct_size != sizeof(ptrwm_run_args)) return PTRWM_E_STRUCT;
-  if (args->state_f64 != 0 || args->reserved0 != 0) return PTRWM_E_ARG;  // float states only
+  if ((args->state_f64 != 0 && args->state_f64 != 1) || args->reserved0 != 0 || args->device_step != nullptr) return PTRWM_E_ARG;
   if (dim < 1 || dim > PTRWM_MAX_DIM) return PTRWM_E_DIM;
   if (args->n_temps < 1 || args->n_temps > PTRWM_MAX_TEMPS) return PTRWM_E_TEMPS;
   if (args->n_chains < 0 || args->n_chains > 0x7fffffffll || args->step0 < 0 || event_index < 0 || rng_stream < 1 ||
@@ -749,6 +843,8 @@ static int32_t split_common_checks(const ptrwm_run_args *args, int32_t dim) {
     return PTRWM_E_ARG;
   if (args->swap_mode != PTRWM_SWAP_EXCHANGE && args->swap_mode != PTRWM_SWAP_REFERENCE_COPY) return PTRWM_E_ARG;
   if (args->swap_order != PTRWM_ORDER_SEQUENTIAL && args->swap_order != PTRWM_ORDER_EVEN_ODD) return PTRWM_E_ARG;
+  if (args->device_step != nullptr && (args->ext_prop != nullptr || args->ext_u != nullptr || args->ext_swap_u != nullptr))
+    return PTRWM_E_ARG;  // device-step mode draws from Philox only
   return PTRWM_OK;
 }
 
@@ -774,7 +870,7 @@ int32_t ptrwm_split_propose(const ptrwm_proposal_desc *proposal, const ptrwm_run
   launch_split_propose<P>(dpi, args->state, proposals, accept_u, args->n_chains, args->chain_offset,                 \
                           (unsigned long long)args->step0, dim, args->n_temps, proposal->temp_scale, pp,             \
                           args->ext_prop, args->ext_prop != nullptr ? args->ext_u : nullptr, n_raw, k0, k1,         \
-                          (hipStream_t)stream)
+                          (const long long *)args->device_step, (hipStream_t)stream)
   switch (proposal->kind) {
     case PTRWM_PROPOSAL_NORMAL: err = PTRWM_SPLIT_CALL(NormalProposal); break;
     case PTRWM_PROPOSAL_LAPLACE: err = PTRWM_SPLIT_CALL(LaplaceProposal); break;
@@ -811,12 +907,37 @@ int32_t ptrwm_split_accept(const ptrwm_run_args *args, int32_t dim, float *propo
   a.dim = dim;
   a.count_on = count_on ? 1 : 0;
   a.swap_due = swap_due ? 1 : 0;
-  hipLaunchKernelGGL(split_accept_kernel, dim3((unsigned)((a.n_reps + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  a.device_step = (const long long *)args->device_step;
+  a.burn_in = args->burn_in;
+  a.swap_every = args->swap_every;
+  {
+    const unsigned lds = 2u * split_tile_lds_bytes(dim);
+    if (lds > 48u * 1024u) {  // (dim > 95: above the default dynamic-LDS allowance; raised once per device)
+      static unsigned long long raised_mask = 0;
+      if (raise_dynamic_lds((const void *)split_accept_kernel, (const void *)split_accept_kernel,
+                            (int)(2u * split_tile_lds_bytes(PTRWM_MAX_DIM)), raised_mask) != hipSuccess)
+        return PTRWM_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(split_accept_kernel, dim3((unsigned)((a.n_reps + 63) / 64)), dim3(64), lds, (hipStream_t)stream, a);
+  }
   if (hipGetLastError() != hipSuccess) return PTRWM_E_LAUNCH;
+  if (args->device_step != nullptr) {
+    // device-step mode: the sweep is enqueued with every step and decides on the device whether its event is due
+    if (args->n_temps < 2) return PTRWM_OK;
+    return launch_sweep(args, dim, 0, (int)kStreamSwap, proposals, args->sq_jump, (hipStream_t)stream);
+  }
   if (!swap_due) return PTRWM_OK;
   // the swap event of this step: event number as ptrwm_run counts them, swap uniforms from the fused kernel's stream
   const long long ev = sc / args->swap_every - args->burn_in / args->swap_every - 1 + args->swap_event_offset;
   return launch_sweep(args, dim, ev, (int)kStreamSwap, proposals, args->sq_jump, (hipStream_t)stream);
+}
+
+int32_t ptrwm_split_advance(const ptrwm_run_args *args, void *stream) {
+  if (args == nullptr) return PTRWM_E_NULL;
+  if (args->struct_size != sizeof(ptrwm_run_args)) return PTRWM_E_STRUCT;
+  if (args->device_step == nullptr) return PTRWM_E_NULL;
+  hipLaunchKernelGGL(split_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long *)args->device_step);
+  return hipGetLastError() == hipSuccess ? PTRWM_OK : PTRWM_E_LAUNCH;
 }
 
 int32_t ptrwm_logdensity(const ptrwm_target_desc *target, const float *x, float *out, int64_t n, void *stream) {

@@ -106,7 +106,8 @@ __device__ __forceinline__ bool mh_accept(float beta_t, float lp_new, float lp, 
 // temperature 0 of its ladder, slot = base + t, us = its swap uniform, my_l = its log-density; s_l / s_u = the
 // ladder's published log-densities and uniforms (already synchronised), landed = one int of LDS scratch per slot;
 // par = parity of the event (even/odd order); sync = the group's barrier (called by every thread of the group, or by
-// none); plain = the group's ladders qualify for the threshold form of the sequential sweep (group-uniform, below).
+// none); plain = this thread's ladder takes the threshold form of the sequential sweep in this event (the same value on
+// every thread of the ladder, below; ladders of one wavefront may differ).
 // Out: my_l = the log-density that ends up at temperature t, src = the slot whose vector does, pair_acc = pair
 // (t, t+1) accepted (recorded on the thread of temperature t).
 //
@@ -119,13 +120,30 @@ __device__ __forceinline__ bool mh_accept(float beta_t, float lp_new, float lp, 
 // three sums, an exponential and two compares per pair to ONE compare per pair (plus the selects that carry the state):
 // ~22 -> ~6 VALU instructions per pair, 4 % of BASELINE configs[2]'s instructions.  Same decisions up to rounding of the
 // threshold (both forms are within a few ulp of the exact boundary; tests prove every decision that differs from the
-// oracle's literal evaluation).  The reference's corner cases keep its literal rule: if any pair of the group has
-// b_j <= b_k, or any replica STARTS the launch with a log-density of -inf or NaN (the reference's four-product sum is then
-// NaN and the swap is refused), the whole group takes the literal scan below for the whole launch - `plain`, voted once
-// per launch by swap_threshold_form(): a finite log-density stays finite (the Metropolis rule never accepts a proposal
-// whose log-density is -inf or NaN).
-__device__ __forceinline__ bool swap_threshold_ok(int T, int t, const float *__restrict__ beta, float beta_t, float lp) {
-  return (t >= T - 1 || sub_rn(beta_t, beta[t + 1]) > 0.0f) && lp > kNegInf;  // (NaN compares false)
+// oracle's literal evaluation).  The reference's corner cases keep its literal rule: a LADDER in which any pair has
+// b_j <= b_k, any replica enters the event with a log-density of -inf or NaN (the reference's four-product sum is then NaN
+// and the swap is refused), or any pair's uniform is exactly 0 or >= 1 (ln u = -inf: the threshold would accept where
+// u < exp(..) with an underflowed exponential refuses; u = 1 can never accept) takes the literal scan below - `plain`, a
+// verdict of the ladder alone, taken at every event from the values it enters the event with (ladder_votes_plain): it
+// cannot depend on which other ladders share the exchange group (kernel form, sharding) nor on where launches are cut.
+// this thread's part of its ladder's verdict: its pair's temperatures are ordered (db = b_t - b_{t+1} > 0), its log-density
+// is finite and its pair's uniform lies strictly inside (0, 1) (the last temperature has no pair: neither db nor the
+// uniform is looked at).  ONE compare: u (1 - u) > 0 exactly for 0 < u < 1, lp * 0 is 0 for a finite log-density and NaN
+// otherwise - three lane masks less in the SGPR file than the four compares spelt out (the run-time-dim lane-split kernels
+// of the dim > 64 class live at the spilled-SGPR ceiling of tools/kernel_stats.py).
+__device__ __forceinline__ bool swap_pair_plain(int T, int t, float db, float lp, float us) {
+  const bool last = t >= T - 1;
+  const float u = last ? 0.5f : us;
+  const float d = last ? 1.0f : db;
+  const float inside = mul_rn(u, sub_rn(1.0f, u));
+  return add_rn(__builtin_fminf(inside, d), mul_rn(lp, 0.0f)) > 0.0f;  // (a NaN anywhere compares false)
+}
+// the AND of `mine` over the `lanes_per_ladder` consecutive lanes of a wavefront that start at `first_lane` (the ladder
+// this thread belongs to), the same value on every one of them
+__device__ __forceinline__ bool ladder_votes_plain(bool mine, int first_lane, int lanes_per_ladder) {
+  const unsigned long long against = __builtin_amdgcn_ballot_w64(!mine);
+  const unsigned long long ladder = (lanes_per_ladder >= 64 ? ~0ull : ((1ull << lanes_per_ladder) - 1ull)) << first_lane;
+  return (against & ladder) == 0ull;
 }
 
 template <class Sync>
@@ -417,7 +435,7 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
   // ordinary global load behind an LDS-DMA makes the compiler drain the DMA at the load's first use, which would put the
   // next group's HBM latency back in front of the current group's step)
   [[maybe_unused]] float beta_t_s = 0.0f, tscale_s = 0.0f;
-  [[maybe_unused]] bool pair_ordered_s = false;  // swap_threshold_ok's condition on the temperatures
+  [[maybe_unused]] float db_s = 1.0f;  // b_t - b_{t+1} of this thread's pair (swap_pair_plain)
   // Outgoing results of the group just finished wait in registers until the NEXT group's rows have been picked up, and
   // are stored then (flush_pending): at the top of an iteration the only vector-memory operations that can still be
   // outstanding are the DMA of the group about to be stepped and the stores issued a whole step earlier - so the wait for
@@ -457,7 +475,7 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
     const int t_s = cw_s < cpw ? tid - cw_s * T : 0;
     beta_t_s = a.beta[t_s];
     tscale_s = a.temp_scale[t_s];
-    pair_ordered_s = swap_threshold_ok(T, t_s, a.beta, beta_t_s, 0.0f);
+    db_s = sub_rn(beta_t_s, a.beta[t_s < T - 1 ? t_s + 1 : t_s]);
     prefetch(group, 0);
   }
   do {
@@ -488,8 +506,6 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
       __builtin_amdgcn_wave_barrier();
     }
   };
-  // does the predicate hold on every thread of the exchange group?  (called by all of them)
-  auto group_all = [&](bool p) -> bool { return wide ? (__syncthreads_and(p ? 1 : 0) != 0) : (__builtin_amdgcn_ballot_w64(!p) == 0ull); };
 
   // ---- state load: coalesced HBM reads staged through LDS ------------------------------------------------
   // The group's live replicas are one contiguous run of n_live * dim floats in `state`.  The group copies that
@@ -534,8 +550,6 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
   }
   const float beta_t = STREAM ? beta_t_s : a.beta[t];
   const float tscale = STREAM ? tscale_s : a.temp_scale[t];
-  // one vote per launch: may the group's sequential sweeps take the threshold form?  (swap_decide)
-  const bool swap_plain = group_all(STREAM ? (pair_ordered_s && lp > kNegInf) : swap_threshold_ok(T, t, a.beta, beta_t, lp));
   // may the proposal's own squared increment stand for |y - x|^2 for this replica?  (proposals.h kJumpTrust)
   bool jump_trusted = false;
   if constexpr (Proposal::kKnowsJump) {
@@ -686,6 +700,9 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
       // publish this thread's log-density and swap uniform; the sweep reads them back with broadcast ds_reads
       s_l[slot] = my_l;
       s_u[slot] = us;
+      // may this ladder's sequential sweep take the threshold form in THIS event?  (swap_decide: a verdict of the ladder)
+      const bool pair_plain = swap_pair_plain(T, t, STREAM ? db_s : sub_rn(beta_t, a.beta[t < T - 1 ? t + 1 : t]), my_l, us);
+      const bool swap_plain = wide ? (__syncthreads_and(pair_plain ? 1 : 0) != 0) : ladder_votes_plain(pair_plain, base, T);
       sync_group();
       swap_decide(T, t, base, slot, a.swap_mode, a.swap_order, (ev_par0 + swap_in_call) & 1, a.beta, beta_t, us, s_l, s_u,
                   reinterpret_cast<int *>(s_u + group_threads), my_l, src, pair_acc, sync_group, swap_plain);
@@ -881,19 +898,39 @@ __global__ void __launch_bounds__(kBlockThreads, standalone_min_waves(DP)) ptrwm
 // ---- split step, first half: proposals for one step written to HBM (targets evaluated by the caller) ----
 // Same Philox words and the same arithmetic as the fused kernel's Proposal::propose call, so a split step driven
 // with the library's own log-density reproduces ptrwm_run bit for bit.
+// One wavefront per 64 replicas (64-thread workgroups): the tile's run of 64 x dim floats goes through a slab of LDS in both
+// directions (stage_copy: coalesced 16-byte transfers whatever the run's alignment), each lane working on its own row -
+// round 3's version read and wrote its row straight from HBM, 64 cache lines per instruction: 0.36 ms per step at
+// 65 536 x 32 x dim 30, where moving the bytes takes 0.1.
+constexpr unsigned split_tile_lds_bytes(int dim) { return (unsigned)(64 * dim + 4) * 4u; }
+
 template <class Proposal, int DP>
-__global__ void __launch_bounds__(kBlockThreads, standalone_min_waves(DP)) ptrwm_split_propose_kernel(
+__global__ void __launch_bounds__(64, standalone_min_waves(DP)) ptrwm_split_propose_kernel(
     const float *__restrict__ state, float *__restrict__ proposals, float *__restrict__ accept_u, long long n_chains,
     long long chain_offset, unsigned long long step, int D, int T, const float *__restrict__ temp_scale, PParams pp,
-    const float *__restrict__ ext_raw, const float *__restrict__ ext_u, int n_raw_ext, unsigned k0, unsigned k1) {
-  const long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
-  if (i >= n_chains * T) return;
+    const float *__restrict__ ext_raw, const float *__restrict__ ext_u, int n_raw_ext, unsigned k0, unsigned k1,
+    const long long *__restrict__ device_step) {
+  extern __shared__ __attribute__((aligned(16))) float s_tile[];
+  const int lane = (int)threadIdx.x;
+  const long long n_reps = n_chains * T;
+  const long long first = (long long)blockIdx.x * 64;
+  if (first >= n_reps) return;
+  if (device_step != nullptr) step = (unsigned long long)*device_step;  // (include/ptrwm.h: graph-capturable split steps)
+  const int n_rows = (n_reps - first < 64) ? (int)(n_reps - first) : 64;
+  const bool live = lane < n_rows;
+  const long long i = first + (live ? lane : 0);
   const long long chain = i / T;
   const int t = (int)(i - chain * T);
   float x[DP], y[DP];
-  const float *__restrict__ xp = state + i * D;
+  float *__restrict__ gx = const_cast<float *>(state) + first * D;
+  stage_copy<true>(s_tile, gx, n_rows * D, lane, 64);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  {
+    const float *row = s_tile + stage_head(gx) + (live ? lane : 0) * D;
 #pragma unroll
-  for (int d = 0; d < DP; ++d) x[d] = (d < D) ? xp[d] : 0.0f;
+    for (int d = 0; d < DP; ++d) x[d] = (d < D) ? row[d] : 0.0f;
+  }
   const unsigned long long gchain = (unsigned long long)(chain_offset + chain);
   RngCtx rc;
   rc.c0hi = (uint32_t)(step >> 32) << 16;
@@ -906,10 +943,19 @@ __global__ void __launch_bounds__(kBlockThreads, standalone_min_waves(DP)) ptrwm
   float jump = 0.0f;
   int jump_kind;
   const float u = Proposal::propose(y, x, D, temp_scale[t], pp, rc, er, ext_u != nullptr ? ext_u[i] : 0.0f, jump, jump_kind);
-  float *__restrict__ op = proposals + i * D;
+  float *__restrict__ gy = proposals + first * D;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();  // every lane has its row in registers: the slab takes the proposals
+  if (live) {
+    float *row = s_tile + stage_head(gy) + lane * D;
 #pragma unroll
-  for (int d = 0; d < DP; ++d)
-    if (d < D) op[d] = y[d];
+    for (int d = 0; d < DP; ++d)
+      if (d < D) row[d] = y[d];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  stage_copy<false>(s_tile, gy, n_rows * D, lane, 64);
+  if (!live) return;
   accept_u[i] = u;
   // second plane of the scratch array: the proposal's own squared jump, exactly as the fused kernel counts it, or -1 when
   // it is to be taken from the states (external randoms, Laplace): split_accept_kernel then reproduces ptrwm_run's sums
@@ -917,7 +963,7 @@ __global__ void __launch_bounds__(kBlockThreads, standalone_min_waves(DP)) ptrwm
 #pragma unroll
   for (int d = 0; d < DP; ++d) xmax = __builtin_fmaxf(xmax, __builtin_fabsf(x[d]));
   const bool trusted = Proposal::kKnowsJump && xmax <= kJumpTrust * Proposal::increment_scale(temp_scale[t], pp);  // (proposals.h)
-  accept_u[n_chains * T + i] = (jump_kind == kJumpTotal && trusted) ? jump : -1.0f;
+  accept_u[n_reps + i] = (jump_kind == kJumpTotal && trusted) ? jump : -1.0f;
 }
 
 }  // namespace ptrwm

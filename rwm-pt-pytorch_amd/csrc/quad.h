@@ -17,7 +17,7 @@
 // Thread map.  slot = tid / 4 (replica within the exchange group), q = tid % 4.  4 T <= 64 ("narrow", T <= 16): an
 // exchange group is one wavefront holding 16 / T whole ladders; a workgroup is four independent wavefronts.
 // T > 16 ("wide"): the exchange group is the workgroup - as many whole ladders as fill 256 threads best, or one ladder in
-// 4 T threads rounded up to whole waves (<= 512, or <= 1024 for the dim > 64 class); barriers for swaps.
+// 4 T threads rounded up to whole waves (<= 512: ladders of up to 128 temperatures); barriers for swaps.
 #pragma once
 #include "kernel.h"
 
@@ -580,16 +580,15 @@ struct QNealFunnel {
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------
 // dynamic LDS bytes of a workgroup: per replica slot a row of up to 4 W state elements (float, or double in the F64 form)
-// plus the six words of kernel.h's swap machinery (log-density, swap uniform, outcome; three spare)
+// plus the words of the swap machinery (per slot: log-density, swap uniform, outcome, the ladder's swap-form objection)
 // -> (W * words-per-element + 2) floats per thread
 constexpr unsigned quad_kernel_lds_bytes(int threads, int w, bool f64 = false) {
   return (unsigned)(threads * (w * (f64 ? 2 : 1) + 2)) * 4u;
 }
 // Widest workgroup = one ladder.  Every variant is compiled for workgroups of up to 512 threads (ladders of <= 128
-// temperatures: up to 256 VGPRs, no spills); the W >= 20 classes (dim > 64), where this is the ONLY form of the fused kernel,
-// are also compiled for 1024 threads (ladders of <= 256 temperatures: 128 VGPRs, a dozen of them spilled).
+// temperatures: up to 256 VGPRs).  (Until round 4 the W >= 20 classes also existed for 1024 threads: 128 VGPRs, 40 of
+// them spilled inside the step loop - retired, variants.h.)
 constexpr int kQuadThreads = 512;
-constexpr int kQuadThreadsMax = 1024;
 
 // double-precision pieces of the F64 form: IEEE ops the compiler must not contract (the state update x + scale * z is then
 // bit-identical to the reference's two float64 torch ops), and the canonical quad combination on 64-bit values
@@ -625,7 +624,7 @@ struct quad_state<true> {
 
 // W      lane register width = canonical range width (8 / 16 / 20 / 24 / 28)
 // DEXACT dim compiled in (0: run-time dim, any value the width class covers)
-// MAXT   largest workgroup the variant may be launched with (kQuadThreads or kQuadThreadsMax)
+// MAXT   largest workgroup the variant may be launched with (kQuadThreads)
 // F64    state_f64 of include/ptrwm.h - the reference's dtype=torch.float64 (pt_rwm_gpu_optimized.py:134,431-449): the state,
 //        the proposal x + scale * z and the squared jump are carried in double (a.state / trace / ext_prop are double arrays);
 //        the increment itself comes from the float proposal functor (Philox) or, with external randoms, is the reference's
@@ -689,6 +688,7 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
     const int stage_total = (int)live_chains * T * D * SW;
     float *__restrict__ gs = a.state + chain0 * T * (long long)D * SW;
     stage_copy<true>(rows_f, gs, stage_total, tid, gthreads);
+    s_landed[nslots + slot_raw] = 0;  // the ladders' swap-form objections (wide groups: the vote of a swap event, below)
     sync_group();
     const state_t *seg = reinterpret_cast<const state_t *>(rows_f + stage_head(gs)) + slot * D + l.d0;
 #pragma unroll
@@ -712,9 +712,6 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
     xmax = __builtin_fmaxf(xmax, dpp_f<kDppSwapHalf>(xmax));
     jump_trusted = xmax <= kJumpTrust * Proposal::increment_scale(tscale, a.pp);
   }
-  // one vote per launch: may the group's sequential sweeps take the threshold form?  (kernel.h swap_decide)
-  const bool swap_plain_here = swap_threshold_ok(T, t, a.beta, beta_t, lp);
-  const bool swap_plain = wide ? (__syncthreads_and(swap_plain_here ? 1 : 0) != 0) : (__builtin_amdgcn_ballot_w64(!swap_plain_here) == 0ull);
 
   const unsigned long long gchain = (unsigned long long)(a.chain_offset + chain);
   RngCtx rc;
@@ -855,7 +852,24 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
       // synchronisations)
       s_l[slot_raw] = my_l;  // the four lanes of a quad write the same value
       s_u[slot_raw] = us;
-      sync_group();
+      // may this ladder's sequential sweep take the threshold form in THIS event?  A verdict of the ladder alone, from the
+      // values it enters the event with (kernel.h swap_pair_plain): narrow groups vote over the ladder's 4 T lanes of the
+      // wavefront; a workgroup holding several whole ladders votes through one flag per ladder behind the outcome slots
+      // (`base` is the ladder's first slot, unique to it)
+      const bool pair_plain = swap_pair_plain(T, t, sub_rn(beta_t, a.beta[t < T - 1 ? t + 1 : t]), my_l, us);
+      bool swap_plain;
+      if (!wide) {
+        swap_plain = ladder_votes_plain(pair_plain, 4 * base, 4 * T);
+        sync_group();
+      } else {
+        // An objection is the event's own stamp (1 + its index in the call) in the ladder's word, written together with
+        // the published values - the one barrier below orders both, the vote has no barrier of its own - and nothing has
+        // to be armed again: the stamp of an earlier event is not this event's.  (The word is read for the last time
+        // before this event's row-exchange barrier, the next objection is written after it.)
+        if (!pair_plain) s_landed[nslots + base] = swap_in_call + 1;
+        sync_group();
+        swap_plain = s_landed[nslots + base] != swap_in_call + 1;
+      }
       if (wide && a.swap_order == PTRWM_ORDER_SEQUENTIAL && a.swap_mode == PTRWM_SWAP_EXCHANGE) {
         // A wide ladder spans several wavefronts; the sequential sweep (kernel.h swap_decide: a scan over the ladder's
         // published values that every thread replays) would be replayed by every one of them - four times the work per
@@ -867,7 +881,7 @@ __global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
           const int b0 = (int)threadIdx.x * T;
           float car_l = s_l[b0];
           int car_i = b0;
-          if (swap_plain) {
+          if (s_landed[nslots + b0] != swap_in_call + 1) {  // the verdict of ladder i (voted above), not of this lane's own ladder
             // (the scanning lane builds each pair's threshold itself - they do not depend on the carried state, so the
             // logs and reciprocals of successive pairs overlap - instead of a third barrier to have them published)
 #pragma unroll 4

@@ -174,12 +174,14 @@ hipError_t launch_logp(const float *x, float *out, long long n, int D, const TPa
 // ---- lane-split ("quad") variants (quad.h): X(lane width W, dim compiled in or 0 for a run-time dim, max threads) ----
 // W is the canonical range width of the dim class (8 / 16 / 20 / 24 / 28 for dim <= 32 / 64 / 80 / 96 / 112); the BASELINE
 // dims get a kernel with dim compiled in, every other dim runs the generic kernel of its class.  The classes above dim 64
-// (W = 20, 24, 28) are the only form of the fused kernel there (see PTRWM_WIDTHS_WIDE above) and therefore also exists for 1024-thread workgroups
-// (ladders of 129..256 temperatures).
+// (W = 20, 24, 28) are the only form of the fused kernel there (see PTRWM_WIDTHS_WIDE above).
+// (Round 4: the 1024-thread class of the dim > 64 kernels - ladders of 129..256 temperatures there - is retired: at the
+// 128 VGPRs a 1024-thread workgroup allows, the W = 28 kernels spilled 41-42 VGPRs into scratch inside the step loop and
+// a dozen more sat above the spilled-SGPR ceiling; a ladder that long at dim > 64 now gets PTRWM_E_NOVARIANT instead of a
+// kernel nobody measured fast.  288 kernels less to build.)
 #define PTRWM_QUAD_WIDTHS(X)                                                                              \
   X(8, 0, kQuadThreads) X(8, 20, kQuadThreads) X(8, 30, kQuadThreads) X(16, 0, kQuadThreads) X(16, 50, kQuadThreads) \
-  X(20, 0, kQuadThreads) X(24, 0, kQuadThreads) X(28, 0, kQuadThreads) X(28, 100, kQuadThreads)                  \
-  X(20, 0, kQuadThreadsMax) X(24, 0, kQuadThreadsMax) X(28, 0, kQuadThreadsMax) X(28, 100, kQuadThreadsMax)
+  X(20, 0, kQuadThreads) X(24, 0, kQuadThreads) X(28, 0, kQuadThreads) X(28, 100, kQuadThreads)
 struct QuadWidthInfo {
   int w, dexact, max_threads;
 };
@@ -237,7 +239,7 @@ inline int quad_index_for(int dim, int n_temps) {
 
 struct QuadVariants {
   RunLaunchFn run[PTRWM_PROPOSAL_COUNT][kNumQuadWidths];
-  RunLaunchFn run_f64[PTRWM_PROPOSAL_COUNT][kNumQuadWidths];  // state_f64 twins (null for the 1024-thread workgroup class)
+  RunLaunchFn run_f64[PTRWM_PROPOSAL_COUNT][kNumQuadWidths];  // state_f64 twins
 };
 
 // MIN_OWN of quad.h: the number of dimensions the LAST lane owns when dim is compiled in (every lane owns at least

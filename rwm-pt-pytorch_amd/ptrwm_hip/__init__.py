@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PTRWM_LIB: alternative build of the same library (A/B tuning experiments)
 LIB_PATH = os.environ.get("PTRWM_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libptrwm_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_DIM = 104
 MAX_TEMPS = 256
 
@@ -115,6 +115,7 @@ class RunArgs(C.Structure):
         ("accept_flags", C.c_void_p),
         ("state_f64", C.c_int32),
         ("reserved0", C.c_int32),
+        ("device_step", C.c_void_p),
     ]
 
 
@@ -131,12 +132,17 @@ SYMBOLS = {
     "ptrwm_has_quad_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "ptrwm_has_thread_variant": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "ptrwm_auto_form": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
+    "ptrwm_auto_form_for": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32]),
+    "ptrwm_device_simds": (C.c_int32, [C.c_void_p]),
+    "ptrwm_source_hash": (C.c_char_p, []),
+    "ptrwm_form_table_source_hash": (C.c_char_p, []),
     "ptrwm_run": (C.c_int32, [C.POINTER(TargetDesc), C.POINTER(ProposalDesc), C.POINTER(RunArgs), C.c_void_p]),
     "ptrwm_swap_sweep": (C.c_int32, [C.POINTER(RunArgs), C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "ptrwm_split_propose": (
         C.c_int32, [C.POINTER(ProposalDesc), C.POINTER(RunArgs), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ptrwm_split_accept": (
         C.c_int32, [C.POINTER(RunArgs), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ptrwm_split_advance": (C.c_int32, [C.POINTER(RunArgs), C.c_void_p]),
     "ptrwm_logdensity": (C.c_int32, [C.POINTER(TargetDesc), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ptrwm_propose": (
         C.c_int32,
@@ -302,6 +308,34 @@ def auto_form(target_kind: int, proposal_kind: int, dim: int, n_temps: int, n_ch
     if rc < 0:
         raise PTRWMError(rc, "ptrwm_auto_form")
     return rc
+
+
+def auto_form_for(target_kind: int, proposal_kind: int, dim: int, n_temps: int, n_chains: int, n_simds: int) -> int:
+    """The AUTO rule for a device of ``n_simds`` SIMDs (a pure function of its arguments and of the fitted table)."""
+    rc = load_library().ptrwm_auto_form_for(target_kind, proposal_kind, dim, n_temps, n_chains, n_simds)
+    if rc < 0:
+        raise PTRWMError(rc, "ptrwm_auto_form_for")
+    return rc
+
+
+def device_simds(device) -> int:
+    """SIMDs (compute units x 4) of ``device`` as the library sees them through the device's current stream."""
+    device = torch.device(device)
+    with on_device(device):
+        rc = load_library().ptrwm_device_simds(_stream(device))
+    if rc < 0:
+        raise PTRWMError(rc, "ptrwm_device_simds")
+    return rc
+
+
+def source_hash() -> str:
+    """sha256 of the kernel sources this library was built from (tools/source_hash.py)."""
+    return load_library().ptrwm_source_hash().decode()
+
+
+def form_table_source_hash() -> str:
+    """Hash of the kernel sources the AUTO form table (csrc/form_table.inc) was fitted on."""
+    return load_library().ptrwm_form_table_source_hash().decode()
 
 
 def set_kernel_form(form: int) -> int:
@@ -506,6 +540,8 @@ class RunPlan:
         if self._t is None:
             raise RuntimeError("this plan has no target description: use split_propose / split_accept")
         a = self._a
+        if a.device_step:
+            raise RuntimeError("device-step mode is for split steps only: set_device_step(None) before launch()")
         a.step0 = step0
         a.n_steps = n_steps
         a.swap_event_offset = swap_event_offset
@@ -562,6 +598,26 @@ class RunPlan:
             self._split = (torch.empty(Cn, T, D, device=self.device, dtype=torch.float32),
                            torch.empty(2, Cn, T, device=self.device, dtype=torch.float32))
         return self._split
+
+    def set_device_step(self, counter: Optional[torch.Tensor]) -> None:
+        """Device-step mode of the split-step calls (include/ptrwm.h `device_step`): ``counter`` is a one-element int64
+        device tensor holding the index of the step to perform; split_propose / split_accept then ignore their ``step``
+        argument, so their argument lists are the same for every step and a sequence of steps can be captured in a HIP
+        graph (``split_advance`` increments the counter as the last node of a step).  ``None`` switches it off."""
+        if counter is not None:
+            if counter.numel() != 1 or counter.device != self.device:
+                raise ValueError("device_step must be a one-element int64 tensor on the run's device")
+            self._a.device_step = _require_device(counter, "device_step", torch.int64)
+        else:
+            self._a.device_step = None
+        self._device_step = counter  # (kept alive)
+
+    def split_advance(self) -> None:
+        """*device_step += 1 on the current stream (ptrwm_split_advance)."""
+        with self._guard:
+            rc = self._lib.ptrwm_split_advance(self._refs[4], _stream(self.device))
+        if rc != 0:
+            raise PTRWMError(rc, "ptrwm_split_advance")
 
     def split_propose(self, step: int, ext_prop: Optional[torch.Tensor] = None,
                       ext_u: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -622,10 +678,10 @@ class RunPlan:
         (stream 1 = the stream the fused kernel's own swap events use)."""
         a = self._a
         Cn, T, D = self.shape
-        if self.state_dtype != torch.float32:
-            raise TypeError("the stand-alone swap sweep takes float32 states (float64 states: the fused kernel only)")
         if ext_swap_u is not None and tuple(ext_swap_u.shape) != (Cn, T - 1):
             raise ValueError(f"ext_swap_u must be [{Cn}, {T - 1}]")
+        if a.device_step:
+            raise RuntimeError("device-step mode is for split steps only: set_device_step(None) before swap_sweep()")
         a.step0 = rng_step
         self._last_trace = (None, None, None)
         a.ext_swap_u = _opt(ext_swap_u, "ext_swap_u", torch.float32)

@@ -45,8 +45,14 @@ class MultivariateNormalTorch(TorchTargetDistribution):
                                 vec0=self.mean.contiguous(), vec1=torch.diagonal(self.cov_inv).contiguous())
 
     def _is_diagonal(self):
-        off_diag = self.cov - torch.diag(torch.diagonal(self.cov))
-        return not bool((off_diag != 0).any())
+        # decided once per covariance (a device -> host read): log_density is called once per step by the split-step path,
+        # which must neither synchronise nor break a HIP-graph capture
+        key = (self.cov.data_ptr(), self.cov._version)
+        if getattr(self, "_diag_key", None) != key:
+            off_diag = self.cov - torch.diag(torch.diagonal(self.cov))
+            self._diag_cached = not bool((off_diag != 0).any())
+            self._diag_key = key
+        return self._diag_cached
 
     def log_density(self, x):
         if self._is_diagonal():

@@ -256,7 +256,7 @@ def test_auto_form_rule_is_the_fitted_model(engine):
     tab = F.load(os.path.join(root, "profiles", "r03_form_sweep_dense.txt"))
     model = F.fit(tab)
     assert F.regret(model, tab, "fit data") > 0.99  # near-ties aside, the rule picks the faster form at every point of its own sweep
-    simds = 1024  # no GPU here: the library assumes an MI355X (256 CUs)
+    simds = 1024  # an MI355X (256 CUs), stated to the library: ptrwm_auto_form_for is a pure function of its arguments
     n = 0
     for dim in (16, 19, 20, 24, 30, 32, 33, 40, 41, 44, 50, 52, 57, 60, 64):
         for T in (1, 2, 5, 8, 16, 20, 32, 48, 64):
@@ -265,14 +265,42 @@ def test_auto_form_rule_is_the_fitted_model(engine):
                 waves = max(1, int(round(w * simds)))
                 C = waves * cpw  # whole waves: w is then exactly waves / simds
                 th, qu = F.rates(model, dim, T, waves / simds)
-                got = engine.auto_form(engine.TARGET_ROUGH_CARPET, engine.PROPOSAL_NORMAL, dim, T, C)
+                got = engine.auto_form_for(engine.TARGET_ROUGH_CARPET, engine.PROPOSAL_NORMAL, dim, T, C, simds)
                 if abs(th - qu) < 2e-3 * max(th, qu):
                     continue  # a tie within the table's four decimals: either form is right
                 assert got == (engine.FORM_QUAD if qu > th else engine.FORM_THREAD), (dim, T, w, C)
                 n += 1
     assert n > 2000
-    assert engine.auto_form(0, 0, 10, 8, 1) == engine.FORM_THREAD      # dim < 16: never lane-split
-    assert engine.auto_form(0, 0, 100, 8, 10**6) == engine.FORM_QUAD   # dim > 64: the only form
-    assert engine.auto_form(0, 0, 30, 32, 65536) == engine.FORM_THREAD  # BASELINE configs[2]: 8 waves per SIMD
+    assert engine.auto_form_for(0, 0, 10, 8, 1, simds) == engine.FORM_THREAD      # dim < 16: never lane-split
+    assert engine.auto_form_for(0, 0, 100, 8, 10**6, simds) == engine.FORM_QUAD   # dim > 64: the only form
+    assert engine.auto_form_for(0, 0, 30, 32, 65536, simds) == engine.FORM_THREAD  # BASELINE configs[2]: 8 waves per SIMD
+    assert engine.auto_form_for(0, 0, 30, 32, 65536, 64 * simds) == engine.FORM_QUAD  # the same batch on 64 times the SIMDs: half a wave each
+    with pytest.raises(engine.PTRWMError):
+        engine.auto_form_for(0, 0, 30, 32, 65536, 0)
     a, q = F.params(model, 30, 1)
     assert a[1] * 1.25 / 2 < a[0]  # the dip of profiles/r02_form_sweep.txt at 81 920 chains
+
+
+def test_form_table_is_stamped_with_the_sources_it_was_fitted_on(engine):
+    """The AUTO form table (csrc/form_table.inc) is a measured artefact: tools/form_fit.py stamps it with the hash of the
+    kernel sources the sweep ran on (tools/source_hash.py) and the library carries the hash of the sources it was built
+    from.  Equal: the table belongs to this build.  Different: a visible warning - AUTO may pick the slower of two
+    bit-identical forms until the sweep is repeated (tools/form_sweep.py dense + tools/form_fit.py); PTRWM_REQUIRE_FRESH_FORM_TABLE=1
+    makes it an error (release check)."""
+    import importlib.util
+    import os
+    import warnings
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("source_hash", os.path.join(root, "tools", "source_hash.py"))
+    S = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(S)
+    built, fitted = engine.source_hash(), engine.form_table_source_hash()
+    assert built == S.source_hash(), "the library was not built from the sources in the tree: rebuild (make -C rwm-pt-pytorch_amd/csrc)"
+    assert len(built) == 64 and fitted
+    if built != fitted:
+        msg = (f"csrc/form_table.inc was fitted on other kernel sources ({fitted[:16]}...) than this library is built from "
+               f"({built[:16]}...): re-fit the AUTO form rule (tools/form_sweep.py dense > sweep; tools/form_fit.py sweep)")
+        assert os.environ.get("PTRWM_REQUIRE_FRESH_FORM_TABLE") != "1", msg
+        warnings.warn(msg)
+

@@ -633,7 +633,7 @@ def test_second_plan_with_large_lds_on_the_same_process(device):
     """The raised dynamic-LDS allowance (> 48 KB: wide ladders at large dims) is set per device inside the library;
     a process that has already run one such plan must be able to build and run a second, different one (and the
     binding needs no torch.cuda.set_device from the caller)."""
-    for dim, T in ((100, 130), (64, 200), (100, 130)):
+    for dim, T in ((100, 128), (64, 200), (100, 128)):
         mean = torch.linspace(-1, 1, dim)
         target = MultivariateNormalTorch(dim, mean=mean.tolist(), cov=torch.diag(torch.linspace(0.5, 2.0, dim)).tolist(),
                                          device=device)
@@ -806,6 +806,59 @@ def test_user_defined_target_runs_in_split_steps(device):
     got = torch.cov(xs.T).cpu()
     assert torch.allclose(got, cov, atol=0.15)
     assert 0.2 < pt.swap_acceptance_rate <= 1.0 and pt.num_swap_attempts == (800 // 5 - 200 // 5) * 2 * 4096
+
+
+def test_split_step_samplers_replay_a_captured_graph(device):
+    """The drop-in classes run a density without a fused kernel through split steps, and - where no per-step trace is
+    asked for - through a HIP graph of 16 steps captured once (algorithms/_engine_core.py _advance_split_graph): the same
+    run with the graph switched off (use_graph = False: one Python iteration per step) gives the same bits, a density
+    that cannot be captured falls back with a warning, and a stand-alone swap event in between re-captures."""
+    cov = torch.tensor([[1.0, 0.8, 0.0], [0.8, 1.0, 0.3], [0.0, 0.3, 2.0]])
+
+    def run(use_graph, sweeps=False):
+        np.random.seed(4)  # (the samplers draw their 1e-8 N(0, 1) starting point from NumPy's global generator)
+        mvn = MultivariateNormalTorch(3, cov=cov, device=device)
+        with pytest.warns(UserWarning, match="split steps"):
+            pt = ParallelTemperingRWM_GPU_Optimized(3, 1.0, mvn, beta_ladder=[1.0, 0.5, 0.25], swap_every=5, burn_in=20,
+                                                    device=device, num_replicas=64, seed=5, trace="none")
+            pt._ensure_started()
+        pt._run.use_graph = use_graph
+        pt._run.advance(70)   # 1 + 4 x 16 + 5
+        if sweeps:
+            pt._attempt_all_swaps()
+        pt._run.advance(41)
+        torch.cuda.synchronize()
+        r = pt._run
+        return {k: getattr(r, k).cpu().numpy() for k in ("state", "logp", "n_accept", "sq_jump", "swap_accept", "last_ord")}, r
+
+    for sweeps in (False, True):
+        a, ra = run(True, sweeps)
+        b, rb = run(False, sweeps)
+        assert ra._graph is not None and rb._graph is None and ra.steps_done == rb.steps_done == 111
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (k, sweeps)
+        assert a["n_accept"].sum() > 0 and a["swap_accept"].sum() > 0
+
+    class _Syncing(_BananaTorch):  # a density that reads a value back to the host: not capturable
+        def log_density(self, x):
+            out = super().log_density(x)
+            float(out.reshape(-1)[0].item())
+            return out
+
+    np.random.seed(4)
+    with pytest.warns(UserWarning):
+        alg = RandomWalkMH_GPU_Optimized(5, 1.2, _Syncing(5, device=device), burn_in=0, device=device, num_chains=32, seed=3)
+        alg._ensure_started()
+        alg._run.advance(40)
+    torch.cuda.synchronize()
+    assert alg._run.steps_done == 40 and alg._run._graph is None and alg._run._graph_failed
+    np.random.seed(4)
+    ref = RandomWalkMH_GPU_Optimized(5, 1.2, _BananaTorch(5, device=device), burn_in=0, device=device, num_chains=32, seed=3)
+    with pytest.warns(UserWarning, match="split steps"):
+        ref._ensure_started()
+    ref._run.use_graph = False
+    ref._run.advance(40)
+    assert torch.equal(ref._run.state, alg._run.state)
 
 
 def test_long_run_statistics_match_the_reference_anchors(device):
@@ -1084,3 +1137,60 @@ def test_pt_class_with_float64_states(device):
     same = (a._run.n_accept == b._run.n_accept).float().mean().item()
     assert same > 0.95  # the two precisions part only where a decision sits on its threshold
     assert torch.allclose(a._run.state.float(), b._run.state, atol=1e-2) or same < 1.0
+
+
+def test_float64_stand_alone_sweep_and_fallbacks(device):
+    """What the reference's scripts do with --use_double_precision beyond generate_samples: `_attempt_all_swaps()` on its own
+    (tests/debug_pt_performance.py:156) works on double states - the stand-alone sweep kernel permutes double rows and makes
+    the decisions the float sweep makes on the same log-densities and uniforms; a target without a fused kernel, or a
+    ladder of more than 128 temperatures, runs in float32 and says so instead of raising."""
+    dim, C = 30, 24
+    target = RoughCarpetDistributionTorch(dim, device=device, mode_centers=[-15.0, 0.0, 15.0])
+
+    def make(dtype):
+        pt = ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target, geom_temp_spacing=True, swap_every=10**6, burn_in=0,
+                                                device=device, num_replicas=C, seed=8, trace="none", dtype=dtype)
+        pt._ensure_started()
+        pt._run.advance(40)  # spread the replicas (no swap events: swap_every is out of reach)
+        return pt
+
+    a, b = make(torch.float64), make(torch.float32)
+    assert a._run.state.dtype == torch.float64
+    # the same states in both precisions from here on (the float run's, exactly representable in double)
+    a._run.state.copy_(b._run.state.double())
+    a._run.logp.copy_(b._run.logp)
+    for _ in range(3):
+        a._attempt_all_swaps()
+        b._attempt_all_swaps()
+    torch.cuda.synchronize()
+    assert torch.equal(a._run.state, b._run.state.double()) and torch.equal(a._run.logp, b._run.logp)
+    assert torch.equal(a._run.swap_accept, b._run.swap_accept) and int(a._run.swap_accept.sum()) > 0
+    assert a.num_swap_attempts == b.num_swap_attempts == 3 * 7 * C
+    # fallbacks: split-step target, very long ladder
+    with pytest.warns(UserWarning, match="float32"):
+        u = ParallelTemperingRWM_GPU_Optimized(5, 1.0, _BananaTorch(5, device=device), beta_ladder=[1.0, 0.5], device=device,
+                                               num_replicas=4, seed=1, trace="none", dtype=torch.float64)
+    assert u.dtype == torch.float32
+    with pytest.warns(UserWarning):
+        u._ensure_started()
+        u._run.advance(3)
+    assert u._run.state.dtype == torch.float32
+    with pytest.warns(UserWarning, match="float32"):
+        w = ParallelTemperingRWM_GPU_Optimized(dim, 2.38**2 / dim, target, beta_ladder=geometric_beta_ladder(130), device=device,
+                                               num_replicas=2, seed=1, trace="none", dtype=torch.float64)
+    assert w.dtype == torch.float32
+    w._ensure_started()
+    w._run.advance(20)
+    assert torch.isfinite(w._run.state).all()
+
+
+def test_auto_form_uses_the_device_that_owns_the_stream(device):
+    """ptrwm_device_simds(stream) is what the AUTO rule scales by (the device of the launch stream, not a constant), and
+    ptrwm_auto_form is ptrwm_auto_form_for at that count."""
+    import ptrwm_hip as P
+
+    n = P.device_simds(device)
+    assert n == 4 * torch.cuda.get_device_properties(device).multi_processor_count
+    for dim, T, Cn in ((30, 32, 65536), (30, 1, 65536), (30, 8, 1), (50, 64, 4096), (20, 4, 30000)):
+        with P.on_device(device):
+            assert P.auto_form(0, 0, dim, T, Cn) == P.auto_form_for(0, 0, dim, T, Cn, n)

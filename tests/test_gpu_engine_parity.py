@@ -841,10 +841,97 @@ def test_split_step_reproduces_the_fused_kernel(device, tkey, pkind, T, pkw):
             assert fused["swap_accept"].sum() > 0
 
 
-@pytest.mark.parametrize("T,dim", [(200, 100), (256, 104), (130, 64), (65, 50)])
+@pytest.mark.parametrize("tkey,pkind,T,pkw,order,mode", [
+    ("rc15_d30", "Normal", 8, dict(base_variance_scalar=2.38**2 / 30), "sequential", "exchange"),
+    ("even_d30", "Laplace", 5, dict(base_variance_vector=np.full(30, 0.004)), "even_odd", "exchange"),
+    ("tm_d50", "UniformRadius", 16, dict(base_radius=2.4), "sequential", "reference_copy"),
+    ("hyb_5_4", "Normal", 1, dict(base_variance_scalar=0.02), "sequential", "exchange"),
+])
+def test_split_steps_from_a_device_step_counter_and_a_captured_graph(device, tkey, pkind, T, pkw, order, mode):
+    """include/ptrwm.h `device_step`: with the step index in device memory no argument of a split step depends on the step,
+    so a block of steps - proposal kernel, the density's kernels, Metropolis kernel, swap kernel, counter increment - is
+    captured ONCE in a HIP graph and replayed.  Eager calls in device-step mode and graph replays both reproduce ptrwm_run
+    bit for bit (states, log-densities, all four statistics; burn-in and the swap schedule are derived from the counter on
+    the device), starting from a step index that is not zero."""
+    spec = H.target_spec(tkey)
+    D = spec.dim
+    beta = (0.02 ** (np.arange(T) / max(1, T - 1))).astype(np.float32) if T > 1 else np.ones(1, np.float32)
+    prop = H.proposal_spec(pkind, D, beta, **pkw) if T > 1 else H.proposal_spec(pkind, D, [1.0], single=True, **pkw)
+    Cn, burn, se, s0 = 9, 7, 4, 3
+    K, replays, tail = 6, 4, 5  # steps per captured graph, replays, eager device-step steps behind them
+    N = 1 + K * replays + tail
+    st0, lp0 = start_state(spec, Cn, T, np.random.default_rng(zlib.crc32(tkey.encode())))
+    kw = dict(beta=beta, burn_in=burn, swap_every=se, seed=321, chain_offset=2, swap_order=E.SWAP_ORDERS[order],
+              swap_mode=E.SWAP_MODES[mode])
+    fused = gpu_run(spec, prop, device, state=st0, logp=lp0, step0=s0, n_steps=N, **kw)
+    st, lp = dev_t(st0, device), dev_t(lp0, device).reshape(Cn, T).contiguous()
+    stats = {k: torch.zeros(Cn, T, dtype=(torch.float64 if k == "sq_jump" else torch.int64), device=device)
+             for k in ("n_accept", "sq_jump", "swap_accept", "last_swap_ordinal")}
+    plan = E.RunPlan(None, prop.engine(device), state=st, logp=lp, beta=dev_t(beta, device), burn_in=burn, swap_every=se,
+                     swap_mode=E.SWAP_MODES[mode], swap_order=E.SWAP_ORDERS[order], seed=321, chain_offset=2, **stats)
+    tgt = spec.engine(device)
+    counter = torch.full((1,), s0, dtype=torch.int64, device=device)
+    plan.set_device_step(counter)
+
+    def step():
+        props = plan.split_propose(10**9)  # (the host-side step argument is ignored in this mode)
+        plan.split_accept(10**9, E.logdensity(tgt, props.view(-1, D)).view(Cn, T))
+        plan.split_advance()
+
+    side = torch.cuda.Stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        step()  # one step outside capture
+    torch.cuda.current_stream(device).wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(K):
+            step()
+    for _ in range(replays):
+        g.replay()
+    for _ in range(tail):
+        step()
+    torch.cuda.synchronize()
+    assert int(counter.item()) == s0 + N
+    assert np.array_equal(st.cpu().numpy(), fused["state"]) and np.array_equal(lp.cpu().numpy(), fused["logp"])
+    for k, v in stats.items():
+        assert np.array_equal(v.cpu().numpy(), fused[k]), k
+    assert fused["n_accept"].sum() > 0 and (T == 1 or fused["swap_accept"].sum() > 0)
+    # the fused kernel and the stand-alone sweep refuse the field; external randoms are refused with it
+    plan.set_device_step(counter)
+    with pytest.raises(RuntimeError, match="device-step"):
+        plan.swap_sweep(0, 0)
+    with pytest.raises(E.PTRWMError):
+        plan.split_propose(0, ext_prop=torch.zeros(Cn, T, E.ext_raw_per_step(prop.kind, D), device=device),
+                           ext_u=torch.zeros(Cn, T, device=device))
+
+
+def test_ladders_beyond_the_compiled_workgroup_are_refused(device):
+    """dim > 64 runs the lane-split kernel only, compiled for workgroups of up to 512 threads = ladders of up to 128
+    temperatures (round 4 retired its 1024-thread class: kernels that spilled 40 VGPRs inside the step loop): a longer
+    ladder there is refused with PTRWM_E_NOVARIANT, through the C ABI and - with a sentence - through the classes."""
+    spec = H.spec_from_params("RoughCarpetDistributionTorch", 100, {"modes": np.float32([-4, 0, 4]), "weights": np.float32([0.2, 0.5, 0.3])})
+    T = 200
+    beta = (0.05 ** (np.arange(T) / (T - 1))).astype(np.float32)
+    prop = H.proposal_spec("Normal", 100, beta, base_variance_scalar=2.38**2 / 100)
+    st, lp = start_state(spec, 2, T, np.random.default_rng(0))
+    with pytest.raises(E.PTRWMError) as ei:
+        gpu_run(spec, prop, device, state=st, logp=lp, beta=beta, step0=0, n_steps=2, seed=1)
+    assert ei.value.code == -8
+    assert not E.has_quad_variant(spec.kind, prop.kind, 100, 129) and E.has_quad_variant(spec.kind, prop.kind, 100, 128)
+    from algorithms import ParallelTemperingRWM_GPU_Optimized
+    from target_distributions import RoughCarpetDistributionTorch
+
+    pt = ParallelTemperingRWM_GPU_Optimized(100, 2.38**2 / 100, RoughCarpetDistributionTorch(100, device=device),
+                                            beta_ladder=[float(b) for b in beta], device=device, num_replicas=2, seed=1, trace="none")
+    with pytest.raises(ValueError, match="128 temperatures"):
+        pt._ensure_started()
+
+
+@pytest.mark.parametrize("T,dim", [(128, 100), (100, 104), (130, 64), (65, 50)])
 def test_wide_ladder_with_large_dim_vs_oracle(device, T, dim):
-    """Wide ladders (one workgroup of ceil(T/64) waves) at large dims: more than 48 KB of dynamic LDS per workgroup
-    (256 threads x 106 floats = 106 KB at dim 104), which needs the raised dynamic-LDS allowance."""
+    """Wide ladders (one workgroup of ceil(T/64) waves, or 4 T lanes in the lane-split form above dim 64) at large dims: more
+    than 48 KB of dynamic LDS per workgroup, which needs the raised dynamic-LDS allowance."""
     rng = np.random.default_rng(T + dim)
     beta = (0.05 ** (np.arange(T) / (T - 1))).astype(np.float32)
     prop = H.proposal_spec("Normal", dim, beta, base_variance_scalar=2.38**2 / dim)
@@ -1076,6 +1163,179 @@ def test_squared_jump_is_that_of_the_stored_states(device, prop_name):
         assert np.abs(want[Cn // 2:] / intended - 1).mean() > 5e-3
 
 
+@pytest.mark.parametrize("prop_name", ["Normal", "UniformRadius"])
+def test_squared_jump_across_the_trust_boundary(device, prop_name):
+    """The verdict whether a replica's squared jumps may be taken from the proposal (largest coordinate within kJumpTrust =
+    256 typical increments) is taken when a launch loads the state and kept for the launch (include/ptrwm.h sq_jump).  A
+    replica that starts INSIDE the trusted range (200-255 increments out) and drifts across the boundary within ONE launch
+    - a Gaussian target centred 600 increments out pulls it there - keeps the verdict it started with; one that starts just
+    outside (257-300) is measured on its states.  Either way the reported sum is the squared distance of its own stored
+    states to 1e-4 relative (the north star's bound is 1e-3), in both kernel forms, bit-identical between them."""
+    dim, Cn, N = 30, 96, 1500
+    scale = 1e-2  # typical increment per dimension
+    var = scale**2
+    prop = H.proposal_spec(prop_name, dim, [1.0], base_variance_scalar=var, base_radius=scale * np.sqrt(dim), single=True)
+    mean = np.zeros(dim, np.float32)
+    mean[0] = 600 * scale
+    prec = np.full(dim, 1.0 / (20 * scale) ** 2, np.float32)  # a well 20 increments wide: a steady pull towards the centre
+    cst = float(-0.5 * dim * np.log(2 * np.pi) + 0.5 * np.log(prec.astype(np.float64)).sum())
+    spec = H.TargetSpec(O.TARGET_DIAG_GAUSSIAN, dim, (cst,), (0,), mean, prec, cls="MultivariateNormalTorch")
+    rng = np.random.default_rng(11)
+    start = np.concatenate([rng.uniform(200, 255, Cn // 2), rng.uniform(257, 300, Cn // 2)]) * scale
+    st = (0.1 * scale * rng.normal(size=(Cn, 1, dim))).astype(np.float32)
+    st[:, 0, 0] = start
+    lp = O.logdensity(spec.oracle(), st.reshape(-1, dim)).reshape(Cn, 1)
+    kw = dict(state=st, logp=lp, beta=np.float32([1.0]), step0=0, n_steps=N, burn_in=0, swap_every=1, seed=9, trace_temps=1)
+    runs = {}
+    for form in (E.FORM_THREAD, E.FORM_QUAD):
+        with E.kernel_form(form):
+            runs[form] = gpu_run(spec, prop, device, **kw)
+    g = runs[E.FORM_THREAD]
+    for k in ("state", "logp", "n_accept", "sq_jump", "trace"):
+        assert np.array_equal(g[k], runs[E.FORM_QUAD][k]), k
+    final = np.abs(g["state"][:, 0, 0]) / scale
+    crossed = (start[: Cn // 2] / scale <= 256) & (final[: Cn // 2] > 256)
+    assert crossed.sum() >= Cn // 4, (crossed.sum(), final[: Cn // 2].min())  # most trusted replicas walk out of the range
+    assert g["n_accept"].min() > 0.1 * N
+    path = np.concatenate([st[None], g["trace"]], axis=0).astype(np.float64)
+    want = (np.diff(path, axis=0) ** 2).sum(axis=(0, 3))[:, 0]
+    err = np.abs(g["sq_jump"][:, 0] / want - 1)
+    assert err[: Cn // 2].max() < 1e-4, err[: Cn // 2].max()   # the proposal's own length, verdict older than the crossing
+    assert err[Cn // 2:].max() < 1e-5, err[Cn // 2:].max()     # measured on the states from the start
+
+
+def test_a_ladder_outside_the_support_changes_nothing_for_its_neighbours(device):
+    """Which scan a ladder's sequential swap sweep takes - the threshold form or the reference's literal rule - is a verdict
+    of the ladder alone, taken at every event from the values it enters the event with (kernel.h swap_pair_plain /
+    ladder_votes_plain): a ladder that starts outside a bounded support (log-density -inf: the literal rule refuses its
+    swaps) must not change the arithmetic of the ladders it shares a wavefront or workgroup with.  Same batch in the
+    one-thread-per-replica form (16 ladders per wavefront), the lane-split form (4 per wavefront), cut into one-step
+    launches, through split steps and through stand-alone sweeps: the same bits everywhere; and every ladder that starts
+    inside the support gets the bits it gets when ALL ladders start inside."""
+    spec = H.target_spec("gamma_d5")
+    D, T, Cn, N, se = 5, 4, 48, 24, 2
+    beta = np.float32([1.0, 0.6, 0.3, 0.1])
+    prop = H.proposal_spec("Laplace", D, beta, base_variance_vector=np.full(D, 0.5))
+    st_in, lp_in = start_state(spec, Cn, T, np.random.default_rng(2))
+    outside = [3, 17, 18, 40]
+    st0, lp0 = st_in.copy(), lp_in.copy()
+    for c in outside:
+        st0[c, 1:, 0] = -1.0 - 0.1 * np.arange(T - 1)  # all but the cold replica outside (0, inf)
+    lp0 = O.logdensity(spec.oracle(), st0.reshape(-1, D)).astype(np.float32).reshape(Cn, T)
+    assert np.isneginf(lp0[outside, 1:]).all() and np.isfinite(lp0[outside, 0]).all()
+    kw = dict(beta=beta, burn_in=0, swap_every=se, seed=77, chain_offset=1)
+    keys = ("state", "logp", "n_accept", "sq_jump", "swap_accept", "last_swap_ordinal")
+    with E.kernel_form(E.FORM_THREAD):
+        ref = gpu_run(spec, prop, device, state=st0, logp=lp0, step0=0, n_steps=N, **kw)
+        clean = gpu_run(spec, prop, device, state=st_in, logp=lp_in, step0=0, n_steps=N, **kw)
+        st, lp, tot = st0, lp0, None
+        for i in range(N):  # one-step launches
+            r = gpu_run(spec, prop, device, state=st, logp=lp, step0=i, n_steps=1, **kw)
+            st, lp = r["state"], r["logp"]
+            tot = r if tot is None else {k: (np.maximum(tot[k], r[k]) if k == "last_swap_ordinal" else tot[k] + r[k]) for k in keys[2:]}
+        assert np.array_equal(st, ref["state"]) and np.array_equal(lp, ref["logp"])
+        for k in ("n_accept", "swap_accept", "last_swap_ordinal"):
+            assert np.array_equal(tot[k], ref[k]), k
+    with E.kernel_form(E.FORM_QUAD):
+        quad = gpu_run(spec, prop, device, state=st0, logp=lp0, step0=0, n_steps=N, **kw)
+    for k in keys:
+        assert np.array_equal(ref[k], quad[k]), k
+    inside = np.setdiff1d(np.arange(Cn), outside)
+    for k in keys:
+        assert np.array_equal(ref[k][inside], clean[k][inside]), k
+    assert ref["swap_accept"][inside].sum() > 0 and ref["n_accept"][outside].sum() > 0
+    # split steps (Metropolis kernel + stand-alone sweep kernel, one workgroup per ladder)
+    std, lpd = dev_t(st0, device), dev_t(lp0, device)
+    stats = {k: torch.zeros(Cn, T, dtype=(torch.float64 if k == "sq_jump" else torch.int64), device=device)
+             for k in ("n_accept", "sq_jump", "swap_accept", "last_swap_ordinal")}
+    plan = E.RunPlan(None, prop.engine(device), state=std, logp=lpd, beta=dev_t(beta, device), burn_in=0, swap_every=se,
+                     seed=77, chain_offset=1, **stats)
+    tgt = spec.engine(device)
+    for i in range(N):
+        props = plan.split_propose(i)
+        plan.split_accept(i, E.logdensity(tgt, props.view(-1, D)).view(Cn, T))
+    torch.cuda.synchronize()
+    assert np.array_equal(std.cpu().numpy(), ref["state"]) and np.array_equal(lpd.cpu().numpy(), ref["logp"])
+    for k, v in stats.items():
+        assert np.array_equal(v.cpu().numpy(), ref[k]), k
+
+
+def test_swap_uniforms_on_the_edges_of_the_unit_interval(device):
+    """A swap uniform of exactly 0 or exactly 1 (external randoms through the C ABI; u = 0 also comes out of the 24-bit
+    lattice once in 1.7e7 draws): the reference's `u < min(1, exp(..))` never accepts u = 1 and refuses u = 0 where the
+    exponential underflows to 0; a ladder holding such a uniform takes the literal scan (kernel.h swap_pair_plain), so the
+    decisions are the oracle's, decision for decision - with pairs whose log-densities differ by thousands among them."""
+    spec = H.target_spec("rc15_d30")
+    D, T, Cn, N = 30, 6, 40, 8
+    beta = (0.05 ** (np.arange(T) / (T - 1))).astype(np.float32)
+    prop = H.proposal_spec("Normal", D, beta, base_variance_scalar=2.38**2 / D)
+    rng = np.random.default_rng(5)
+    st = rng.normal(0, 1.0, (Cn, T, D)).astype(np.float32)
+    st[:, ::2] *= 30.0  # every other rung far out: log-densities thousands apart, exp underflows
+    lp = O.logdensity(spec.oracle(), st.reshape(-1, D)).astype(np.float32).reshape(Cn, T)
+    es = rng.random((N, Cn, T - 1)).astype(np.float32)
+    es[:, ::3, 0] = 0.0
+    es[:, 1::3, 2] = 1.0
+    es[:, 2::3, 4] = 0.0
+    kw = dict(state=st, logp=lp, beta=beta, step0=0, n_steps=N, burn_in=0, swap_every=1, seed=3,
+              ext_prop=np.zeros((N, Cn, T, D), np.float32), ext_u=np.full((N, Cn, T), 2.0, np.float32), ext_swap_u=es)
+    # (zero increments and accept uniforms of 2: the Metropolis step keeps every state - the run is swap events only)
+    want = O.run(spec.oracle(), prop.oracle(), state=st.copy(), logp=lp.copy(), beta=beta, step0=0, n_steps=N, burn_in=0,
+                 swap_every=1, seed=3, ext_prop=kw["ext_prop"], ext_u=kw["ext_u"], ext_swap_u=es)
+    for form in (E.FORM_THREAD, E.FORM_QUAD):
+        with E.kernel_form(form):
+            got = gpu_run(spec, prop, device, **kw)
+        assert np.array_equal(got["swap_accept"], want["swap_accept"]), form
+        assert np.array_equal(got["state"], want["state"]) and np.array_equal(got["last_swap_ordinal"], want["last_swap_ordinal"])
+    assert want["swap_accept"].sum() > 0
+
+
+@pytest.mark.parametrize("name", ["configs1_rwm_rc15_normal", "configs2_pt_rc15_normal", "configs3_pt_even_laplace",
+                                  "configs4_pt_tm50_uniform"])
+def test_long_free_running_philox_runs_match_the_oracle(device, name):
+    """The production path on its own over a long horizon: 11 000 steps (burn-in 1 000) of in-kernel Philox, never
+    restarted, for each BASELINE family, against the C oracle's free run on the same Philox stream
+    (tests/golden/oracle_free_runs.json, tests/golden/generate_oracle_free_runs.py: 8 192 replicas per family).  The two
+    follow the same trajectories until an fp32-level flip (proven decision by decision in check_parity_philox) and sample
+    the same chain afterwards: per-temperature Metropolis acceptance, per-temperature mean squared jump and the swap
+    fraction agree at 1e-3 relative + 4 combined standard errors (errors over ladders)."""
+    import importlib.util
+    import json
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec_ = importlib.util.spec_from_file_location("free_runs", os.path.join(here, "golden", "generate_oracle_free_runs.py"))
+    G = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(G)
+    with open(os.path.join(here, "golden", "oracle_free_runs.json")) as f:
+        anchors = json.load(f)
+    fam = anchors["families"][name]
+    tkey, pkind, pkw, T, Cn = G.FAMILIES[name]
+    assert (anchors["burn_in"], anchors["steps"], anchors["swap_every"], anchors["seed"]) == (G.BURN, G.STEPS, G.SE, G.SEED)
+    assert fam["ladders"] == Cn and fam["temps"] == T
+    spec = H.target_spec(tkey)
+    beta = G.ladder(T)
+    prop = H.proposal_spec(pkind, spec.dim, beta, **pkw) if T > 1 else H.proposal_spec(pkind, spec.dim, [1.0], single=True, **pkw)
+    st, lp = G.start(spec, Cn, T)
+    r = gpu_run(spec, prop, device, state=st, logp=lp, beta=beta, step0=0, n_steps=G.BURN + G.STEPS, burn_in=G.BURN,
+                swap_every=G.SE, seed=G.SEED, chain_offset=0)
+
+    def close(got, want, se_want, what):
+        got = np.asarray(got, np.float64)
+        m, se = got.mean(0), got.std(0, ddof=1) / np.sqrt(got.shape[0])
+        want, se_want = np.asarray(want), np.asarray(se_want)
+        tol = 1e-3 * np.abs(want) + 4 * np.sqrt(se**2 + se_want**2)
+        assert np.all(np.abs(m - want) <= tol), (what, float(np.max(np.abs(m - want) / tol)))
+
+    close(r["n_accept"] / G.STEPS, fam["acceptance"]["mean"], fam["acceptance"]["stderr"], "acceptance")
+    close(r["sq_jump"] / G.STEPS, fam["mean_sq_jump"]["mean"], fam["mean_sq_jump"]["stderr"], "mean squared jump")
+    if T > 1:
+        events = (G.BURN + G.STEPS) // G.SE - G.BURN // G.SE
+        frac = r["swap_accept"][:, :T - 1].sum(1) / (events * (T - 1))
+        close(frac[:, None], [fam["swap_fraction"]["mean"]], [fam["swap_fraction"]["stderr"]], "swap fraction")
+        assert 0.02 < fam["swap_fraction"]["mean"] < 0.98
+    assert 0.01 < fam["acceptance"]["mean"][0] < 0.9
+
+
 def test_float64_argument_validation(device):
     spec = H.target_spec("rc15_d30")
     st = torch.zeros(2, 1, 30, device=device, dtype=torch.float64)
@@ -1090,8 +1350,8 @@ def test_float64_argument_validation(device):
         E.run(spec.engine(device), lap.engine(device), state=st, logp=lp, beta=b, step0=0, n_steps=1,
               trace=torch.zeros(1, 2, 1, 30, device=device))
     plan = E.RunPlan(spec.engine(device), lap.engine(device), state=st, logp=lp, beta=b)
-    with pytest.raises(TypeError, match="float32 states"):
-        plan.swap_sweep(0, 0)
+    with pytest.raises(TypeError, match="float32 states"):  # split steps carry float states
+        plan.split_propose(0)
     with pytest.raises(TypeError, match="float32 or torch.float64"):
         E.RunPlan(spec.engine(device), lap.engine(device), state=st.half(), logp=lp, beta=b)
     E.run(spec.engine(device), lap.engine(device), state=st, logp=lp, beta=b, step0=0, n_steps=3, seed=1)  # Philox: any proposal

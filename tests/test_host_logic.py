@@ -419,7 +419,8 @@ def test_abi_calls_run_with_the_tensors_device_current(monkeypatch):
     src = inspect.getsource(ptrwm_hip)
     host_only = ("ptrwm_strerror", "ptrwm_abi_version", "ptrwm_ext_raw_per_step", "ptrwm_has_variant",
                  "ptrwm_has_quad_variant", "ptrwm_has_thread_variant", "ptrwm_auto_form", "ptrwm_set_kernel_form",
-                 "ptrwm_set_stream_mode", "ptrwm_has_stream_variant", "ptrwm_last_launch_kind")  # no launch behind these
+                 "ptrwm_set_stream_mode", "ptrwm_has_stream_variant", "ptrwm_last_launch_kind", "ptrwm_auto_form_for",
+                 "ptrwm_source_hash", "ptrwm_form_table_source_hash")  # no launch behind these
     calls = [ln for ln in src.splitlines() if "lib.ptrwm_" in ln and "(" in ln and not any(h in ln for h in host_only)]
     assert len(calls) >= 7
     lines = src.splitlines()

@@ -119,6 +119,9 @@ def main():
         regret(model, load(sys.argv[2]), "held-out data")
     f = lambda v: ", ".join(f"{x:.4f}f" for x in v)  # noqa: E731
     print(f"// generated by tools/form_fit.py from {sys.argv[1]} - do not edit; see the tool for the model")
+    stamp = next((l.split()[2] for l in open(sys.argv[1]) if l.startswith("# source_hash ")), None)
+    print("// the kernel sources the sweep was measured on (tools/source_hash.py; ptrwm_form_table_source_hash())")
+    print(f'constexpr char kFormTableSourceHash[] = "{stamp or "unknown (the sweep carries no source_hash line)"}";')
     print(f"constexpr int kFormDims[] = {{{', '.join(map(str, dims))}}};")
     print(f"constexpr bool kFormDimExact[] = {{{', '.join('true' if d in EXACT_DIMS else 'false' for d in dims)}}};  // a kernel with this dim compiled in")
     print(f"constexpr int kFormTemps[] = {{{', '.join(map(str, temps))}}};")

@@ -40,6 +40,7 @@ def dense(held_out=False):
     # the fit grid: the dims with a kernel of their own (dim compiled in: 20, 30, 50) and, for all the others, dims across the
     # generic register widths; held out: other generic dims, and the compiled-in ones at other batch sizes
     dims = (18, 22, 26, 30, 38, 46, 50, 54, 62) if held_out else (16, 20, 24, 28, 30, 32, 36, 40, 44, 48, 50, 52, 56, 60, 64)
+    print(f"# source_hash {E.source_hash()}")  # the kernels this sweep measures (tools/form_fit.py stamps the table with it)
     print(f"{'dim':>4} {'T':>4} {'chains':>7} {'w':>5} {'thread':>10} {'quad':>10} {'auto':>10} {'auto/best':>9}")
     worst = 1.0
     for dim in dims:

@@ -94,6 +94,8 @@ def main():
         spec, x0 = random_target(rng, dim)
         dim = spec.dim
         T = int(rng.choice([1, 2, 3, 5, 8, 21, 32, 33, 64, 65, 100, 130, 200, 256]))
+        if dim > 64 and T > 128:
+            T = 128  # above dim 64 (lane-split kernel only, 512-thread workgroups) a ladder holds at most 128 temperatures
         Cn = int(rng.integers(1, 6)) if T > 64 else int(rng.integers(1, 40))
         beta = (0.03 ** (np.arange(T) / max(1, T - 1))).astype(f32)
         pk = str(rng.choice(["Normal", "Laplace", "UniformRadius"]))

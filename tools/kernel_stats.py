@@ -27,6 +27,10 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 PROD_SGPR_SPILL_CEILING = 96  # ratchet: 163 when introduced in round 3 (HybridRosenbrock<64> + UniformRadius thread form, now 34); 96 at the end of round 3 = the largest production kernel (a run-time-dim lane-split W = 28 kernel, 94) + the +-2 the count moves by between builds of unrelated changes; lower it when that kernel improves, never raise it
+QUAD_SCRATCH_CEILING = 128  # bytes per thread, production lane-split kernels (round 4; a ratchet: lower it, never raise it): worst when introduced 120 B - the double-state (state_f64) twins of the run-time-dim W = 28 kernels, dims 97..104; float kernels: at most 36 B; the 1024-thread class that spilled 204 B inside the step loop is retired
+STREAM_SCRATCH_CEILING = 96  # bytes per thread, streaming twins (ratchet): worst when introduced 80 B (RoughCarpet<50> + Normal, at the 256-VGPR gate with one wave per SIMD resident); dims <= 30: none
+MAX_KERNELS = 3200  # budget: every (target, proposal, width, twin) is a kernel to build, ship and keep correct (3 099 at the end of round 3, 3 387 with the streaming twins, 3 101 after retiring the 1024-thread lane-split class)
+MAX_LIBRARY_BYTES = 88 << 20  # budget for libptrwm_hip.so (--size, run by the Makefile after the link)
 STREAM_SGPR_SPILL_CEILING = 128  # the streaming twins (round 4; kernel.h STREAM): their own ratchet - the loop over groups keeps a dozen more scalars alive across the step than the classic kernel's single pass (worst when introduced: Hypercube<50> + UniformRadius, whose verdict is a chain of 64-bit lane masks)
 COLD_SCRATCH_BYTES = 64  # see the scratch rule in main()
 FIELDS = ("agpr_count", "vgpr_count", "vgpr_spill_count", "sgpr_count", "sgpr_spill_count", "private_segment_fixed_size",
@@ -59,6 +63,13 @@ def short(name):
 
 def main():
     args = sys.argv[1:]
+    if "--size" in args:  # python tools/kernel_stats.py --size <libptrwm_hip.so>: the library-size budget (Makefile, after the link)
+        path = args[args.index("--size") + 1]
+        size = os.path.getsize(path)
+        if size > MAX_LIBRARY_BYTES:
+            sys.exit(f"kernel_stats --size: {path} is {size / 2**20:.1f} MiB, budget {MAX_LIBRARY_BYTES / 2**20:.0f} MiB")
+        print(f"kernel_stats --size: {os.path.basename(path)} {size / 2**20:.1f} MiB (budget {MAX_LIBRARY_BYTES / 2**20:.0f} MiB)")
+        return
     check = "--check" in args
     args = [a for a in args if a != "--check"]
     objdir = os.path.join(ROOT, "rwm-pt-pytorch_amd", "build")
@@ -109,6 +120,9 @@ def main():
                 if m["vgpr_count"] > 256 or m["agpr_count"] > 0:
                     bad.append(f"{base}: {short(name)} needs vgpr_count {m['vgpr_count']}, agpr_count {m['agpr_count']} "
                                "(limit 256 / 0): the register regime hipcc miscompiled twice")
+                if production and "quad_step_kernel" in name and m["private_segment_fixed_size"] > QUAD_SCRATCH_CEILING:
+                    bad.append(f"{base}: production lane-split kernel {short(name)} uses {m['private_segment_fixed_size']} B of "
+                               f"scratch (ceiling {QUAD_SCRATCH_CEILING})")
                 if production and m["private_segment_fixed_size"] > 0:
                     msg = f"{base}: production kernel {short(name)} uses {m['private_segment_fixed_size']} B of scratch"
                     # The rule guards the step loop: an array that went to scratch (dynamic indexing: >= 4 x width bytes, found
@@ -116,13 +130,17 @@ def main():
                     # the register cap - written before the loop, read back in the epilogue or in a swap event - are
                     # tolerated up to COLD_SCRATCH_BYTES; tools/issue_model.py checks that the Metropolis-step path of the
                     # headline kernel contains no scratch store and at most one reload.
-                    (bad if (maxilp and m["private_segment_fixed_size"] > COLD_SCRATCH_BYTES) else notes).append(msg)
-                    if maxilp:
+                    limit = STREAM_SCRATCH_CEILING if streaming else COLD_SCRATCH_BYTES
+                    (bad if (maxilp and m["private_segment_fixed_size"] > limit) else notes).append(msg)
+                    if maxilp and not streaming:
                         worst_scratch = max(worst_scratch, (m["private_segment_fixed_size"], f"{base}: {short(name)}"))
             elif flt in name or flt in short(name):
                 print(f"{base:34s} {short(name):95s} vgpr {m['vgpr_count']:3d} agpr {m['agpr_count']:2d} vspill "
                       f"{m['vgpr_spill_count']:3d} sgpr {m['sgpr_count']:3d} sspill {m['sgpr_spill_count']:3d} scratch "
                       f"{m['private_segment_fixed_size']:4d} lds {m['group_segment_fixed_size']}")
+    if check and n > MAX_KERNELS:
+        bad.append(f"{n} kernels in the build, budget {MAX_KERNELS}: every variant axis multiplies build time, library size and "
+                   "the surface the oracle checks have to cover - retire something before adding")
     if check:
         if notes:
             print(f"note: {len(notes)} production kernels outside the max-ILP group use scratch, e.g. {notes[0]}")
