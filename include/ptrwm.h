@@ -215,7 +215,12 @@ typedef struct ptrwm_run_args {
                          * accepted Metropolis move of the Normal / UniformRadius proposals in Philox mode this is the
                          * squared length of the increment itself, which equals that of the float sum x + inc to ~3e-5
                          * relative or better wherever it is used: a replica whose largest |coordinate| exceeds 256
-                         * typical increments when a launch loads it takes the jump from the states instead. */
+                         * typical increments when a launch loads it takes the jump from the states instead.
+                         * That choice is made once per LAUNCH, from the state the launch starts with: state, logp and
+                         * every counter are independent of how a run is cut into launches, sq_jump is too unless a
+                         * replica crosses that bound in the middle of a launch - then the two cuts differ in the last
+                         * bits of that replica's sum (both within the ~3e-5 above; the oracle follows the same rule
+                         * per launch, tests/test_gpu_engine_parity.py test_squared_jump_across_the_trust_boundary). */
   int64_t *swap_accept; /* [n_chains, n_temps] accepted swaps of pair (t, t+1); column n_temps-1 unused */
   int64_t *last_swap_ordinal; /* [n_chains, n_temps] max 1-based attempt ordinal at which pair t accepted */
   /* schedule: this call performs steps step0 .. step0+n_steps-1 (0-based); step i has

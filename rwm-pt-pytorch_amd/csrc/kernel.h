@@ -26,10 +26,11 @@ namespace ptrwm {
 constexpr int kBlockThreads = PTRWM_BLOCK_THREADS;
 constexpr int kWavesPerBlock = kBlockThreads / 64;
 // dynamic LDS bytes of a step-kernel workgroup of `threads` threads with register width dp: one row of dp floats
-// per thread plus its log-density, swap-uniform and swap-outcome slots and three words that live for the whole
+// per thread plus its log-density, swap-uniform and swap-outcome slots, three words that live for the whole
 // launch but are touched only in swap events and the epilogue (parked in LDS to keep them out of the VGPR budget
-// of the MH part: without that the compiler spilled five VGPRs to scratch, 42 MB of HBM traffic per launch)
-constexpr int kLdsExtraPerThread = 6;  // s_l, s_u, landed (swap-event scratch); c3, swap count, last event (whole launch)
+// of the MH part: without that the compiler spilled five VGPRs to scratch, 42 MB of HBM traffic per launch) and the
+// launch's sum of squared jumps (a double: two words, added to by ds_add_f64 - profiles/r04_scratch_ab.txt)
+constexpr int kLdsExtraPerThread = 8;  // s_l, s_u, landed (swap-event scratch); c3, swap count, last event, the squared-jump sum (a double) (whole launch)
 // (the streaming form, STREAM below, keeps TWO slabs of rows per wave: the one its current group lives in and the one the
 // next group's state is landing in)
 // and two small landing zones for the next group's log-densities (one float per thread), squared-jump sums (one double) and
@@ -42,6 +43,9 @@ constexpr int lds_floats_per_thread(int dp, bool stream) {
 constexpr unsigned step_kernel_lds_bytes(int threads, int dp, bool stream = false) {
   return (unsigned)(threads * lds_floats_per_thread(dp, stream)) * 4u;
 }
+// a wide group (one ladder = the workgroup, n_temps > 64) has one more word behind all of that: the ladder's objection to
+// the threshold form of a swap event (ptrwm_step_kernel, the swap section)
+constexpr unsigned kWideVoteBytes = 16u;
 
 // Arguments only the fixture / trace variant of the kernel (FULL = true) reads.  Keeping them out
 // of the production variant keeps its wave-uniform state inside the 100-odd SGPRs of a wave.
@@ -489,7 +493,7 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
   const long long chain = chain0 + cw;
   const long long rep = chain0 * T + (live ? tid : 0);  // cw * T + t == tid for a live thread
 
-  // ---- LDS (dynamic: group threads * (DP + 3) floats per group, sized by the launch: step_kernel_lds_bytes) --
+  // ---- LDS (dynamic: group threads * (DP + kLdsExtraPerThread) floats per group, sized by the launch: step_kernel_lds_bytes) --
   // s_stage: one row of up to DP floats per thread; the group packs its live replicas' rows back to back (row
   // stride = dim) for the coalesced state load / store and exchanges rows through it in a swap.
   // s_l / s_u / landed (behind the rows): per-thread log-density, swap uniform and swap outcome of a swap sweep.
@@ -522,6 +526,7 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
     if constexpr (!STREAM) {
       stage_copy<true>(s_stage, gs, stage_total, tid, nthr);
       row_head = stage_head(gs);
+      if (wide) reinterpret_cast<int *>(s_dyn)[nthr * (DP + kLdsExtraPerThread)] = 0;  // no objection yet (kWideVoteBytes)
     }
     // (streaming form: the run is landing in slab `cur` by LDS-DMA.  The compiler does not order LDS reads behind it:
     // this wait does - every DMA of this wave, and nothing younger than a whole step, see flush_pending)
@@ -575,8 +580,14 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
     park[0] = (int)c3_base;
     park[gt] = 0;
     park[2 * gt] = -1;
+    // ... and this launch's sum of squared jumps, a double behind them: added to by a no-return ds_add_f64 per counted
+    // step - the same IEEE additions in the same order as a register would see, without the two VGPRs of a double that
+    // lives across the whole step loop (the headline kernel sits at the 128-VGPR cap of four waves per SIMD)
+    reinterpret_cast<double *>(park - tid + 3 * gt)[tid] = 0.0;
   }
-  double sq = 0.0;
+#ifdef PTRWM_NO_SQ_LDS
+  double sq_reg = 0.0;
+#endif
 
   const bool ext = FULL && a.full.ext_prop != nullptr;
   const bool trace_on =
@@ -598,6 +609,12 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
     rc.c0hi = (uint32_t)(s >> 32) << 16;
     rc.c1 = (uint32_t)s;
     rc.c3 = c3_base | (kStreamMH << 8);
+    // (the chain word is made opaque per step: its product with the Philox multiplier is otherwise hoisted out of the step
+    // loop as a 64-bit pair, which at the register cap is spilled and fetched back from scratch at the top of every step -
+    // one v_mad_u64_u32 per step instead)
+#ifndef PTRWM_NO_C2_OPAQUE
+    asm volatile("" : "+v"(rc.c2));
+#endif
 
     long long srep = 0;
     const float *ext_raw = nullptr;
@@ -702,8 +719,19 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
       s_u[slot] = us;
       // may this ladder's sequential sweep take the threshold form in THIS event?  (swap_decide: a verdict of the ladder)
       const bool pair_plain = swap_pair_plain(T, t, STREAM ? db_s : sub_rn(beta_t, a.beta[t < T - 1 ? t + 1 : t]), my_l, us);
-      const bool swap_plain = wide ? (__syncthreads_and(pair_plain ? 1 : 0) != 0) : ladder_votes_plain(pair_plain, base, T);
-      sync_group();
+      // (narrow groups: a ballot over the ladder's lanes.  Wide: an objection is the event's stamp in the ladder's word
+      // behind the parked words, written together with the published values - the one barrier orders both - and read
+      // for the last time before this event's row-exchange barrier, after which the next event may stamp it again)
+      bool swap_plain;
+      if (wide) {
+        int *const objection = reinterpret_cast<int *>(s_l + kLdsExtraPerThread * group_threads);
+        if (!pair_plain) *objection = swap_in_call + 1;
+        sync_group();
+        swap_plain = *objection != swap_in_call + 1;
+      } else {
+        swap_plain = ladder_votes_plain(pair_plain, base, T);
+        sync_group();
+      }
       swap_decide(T, t, base, slot, a.swap_mode, a.swap_order, (ev_par0 + swap_in_call) & 1, a.beta, beta_t, us, s_l, s_u,
                   reinterpret_cast<int *>(s_u + group_threads), my_l, src, pair_acc, sync_group, swap_plain);
       if (pair_acc) {
@@ -734,7 +762,17 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
 
     if (count_on) {
       n_acc += acc ? 1u : 0u;
-      sq += (double)j2;
+#ifdef PTRWM_NO_SQ_LDS
+      sq_reg += (double)j2;
+#else
+      const int tid_q = thread_index_now(wave);  // (the slot's address is rebuilt here, not carried across the step)
+      const int gt_q = wide ? ((T + 63) & ~63) : 64;
+      double *const sq_slot = reinterpret_cast<double *>(
+                                  STREAM ? s_dyn + wave * kWaveFloats + kExtra0 + 6 * 64
+                                         : s_dyn + (wide ? 0 : wave * (64 * (DP + kLdsExtraPerThread))) + gt_q * (DP + 6)) +
+                              (wide ? tid_q : (tid_q & 63));
+      (void)__hip_atomic_fetch_add(sq_slot, (double)j2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
     }
     if constexpr (FULL) {
       bool trace_now = false;
@@ -810,6 +848,12 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
     const int t = park[0] & 0xff;
     const unsigned n_swap_acc = (unsigned)park[gt_o];
     const int last_event = park[2 * gt_o];
+    const int tid_g = T_o > 64 ? tid_o : (tid_o & 63);
+#ifdef PTRWM_NO_SQ_LDS
+    const double sq = sq_reg;
+#else
+    const double sq = reinterpret_cast<const double *>(park - tid_g + 3 * gt_o)[tid_g];
+#endif
     if constexpr (STREAM) {
       // handed to flush_pending (the old squared-jump sum came in with the prefetch: the same double addition as the classic
       // kernel's read-modify-write, without a load)

@@ -629,8 +629,14 @@ struct quad_state<true> {
 //        the proposal x + scale * z and the squared jump are carried in double (a.state / trace / ext_prop are double arrays);
 //        the increment itself comes from the float proposal functor (Philox) or, with external randoms, is the reference's
 //        double product of the float scale and a double normal; the log-density is evaluated on the proposal rounded to float
+// Register budget (second __launch_bounds__ argument: waves per SIMD the allocation must allow).  The float kernels of
+// the widest class need 173 - 176 VGPRs unconstrained - a handful over the 168 that let a third wave share the SIMD -
+// and fit 168 with at most 24 B of scratch (compiled-in dim 100: none); everything else is left to the allocator
+// (W <= 24: already <= 168; double state: 256; the FULL twins trace to HBM anyway).
+constexpr int quad_min_waves(int w, bool f64, bool full) { return (w >= 28 && !f64 && !full) ? 3 : 1; }
+
 template <class Target, class Proposal, int W, int DEXACT, int MAXT, bool FULL, bool F64 = false>
-__global__ void __launch_bounds__(MAXT) ptrwm_quad_step_kernel(const KArgs a) {
+__global__ void __launch_bounds__(MAXT, quad_min_waves(W, F64, FULL)) ptrwm_quad_step_kernel(const KArgs a) {
   typedef typename quad_state<F64>::type state_t;
   constexpr int SW = F64 ? 2 : 1;  // 32-bit words per state element
   const int T = a.n_temps;

@@ -61,8 +61,11 @@ __device__ __forceinline__ void rc_dim_term(float d0, float d1, float d2, float 
 // ~1 500-instruction step loop moves by several per cent with the placement of the fences; candidates are A/B-timed on
 // one box (tools/ab_bench.sh).  With the canonical four-range sums a fence every 4 dimensions cost 3.5 % on BASELINE
 // configs[2] (113.4 against 109.5 ms per 2 000-step launch); 8, 16 and no fences measured the same (109.2-109.5).
+// Round 4: with the squared-jump sum parked in LDS the headline kernel needs 127 VGPRs and no scratch, and then a fence
+// every 16 dimensions (or none) is 2.5 % faster than every 8 - 93.0 against 95.5 ms, and the same whatever the cadence
+// of the update loop's fences (profiles/r04_scratch_ab.txt).
 #ifndef PTRWM_RC_FENCE_MASK
-#define PTRWM_RC_FENCE_MASK 7
+#define PTRWM_RC_FENCE_MASK 15
 #endif
 
 template <int DP, bool TWO_TERM>

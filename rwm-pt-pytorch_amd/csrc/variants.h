@@ -147,13 +147,13 @@ hipError_t launch_run(const KArgs &a, unsigned grid, int mode, hipStream_t strea
   // narrow ladders: four independent one-wave groups per workgroup; wide ones (n_temps > 64): as many waves as
   // the ladder needs
   const unsigned block = a.n_temps > 64 ? (unsigned)((a.n_temps + 63) & ~63) : (unsigned)kBlockThreads;
-  const unsigned lds = step_kernel_lds_bytes((int)block, DP);
+  const unsigned lds = step_kernel_lds_bytes((int)block, DP) + (a.n_temps > 64 ? kWideVoteBytes : 0u);
   auto kfull = ptrwm_step_kernel<Target, Proposal, DP, EXACT, true>;
   auto kprod = ptrwm_step_kernel<Target, Proposal, DP, EXACT, false>;
   if (lds > 48u * 1024u) {  // above the default dynamic-LDS allowance (wide ladders at large dim)
     static unsigned long long raised_mask = 0;
     const hipError_t e = raise_dynamic_lds((const void *)kfull, (const void *)kprod,
-                                           (int)step_kernel_lds_bytes(kBlockThreads, DP), raised_mask);
+                                           (int)(step_kernel_lds_bytes(kBlockThreads, DP) + kWideVoteBytes), raised_mask);
     if (e != hipSuccess) return e;
   }
   if (full)

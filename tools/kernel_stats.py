@@ -9,10 +9,10 @@
 widths 80 / 100 twice: in round 1 under the max-ILP scheduler (profiles/r02_miscompile_width80.txt), in round 2 under the
 DEFAULT scheduler after a scheduling fence moved.  Those kernels are retired (dim > 64 runs the lane-split kernel); the
 gate keeps any future kernel out of that regime.
-It also fails if a PRODUCTION step kernel (FULL = false) of the max-ILP group (variants_*.o) uses more than 64 bytes of
-scratch memory per thread (round 2 found and fixed 16 + 4 DP bytes per thread in every HybridRosenbrock kernel this way: an
-array the optimiser had made dynamically indexed; up to 64 bytes are loop-invariant words parked there at the register cap,
-outside the Metropolis-step path); scratch elsewhere (the 1024-thread lane-split variants of the dim > 64 class spill a dozen VGPRs) is reported;
+It also fails if a PRODUCTION step kernel (FULL = false) of the max-ILP group (variants_*.o) uses ANY scratch memory
+(round 2 found and fixed 16 + 4 DP bytes per thread in every HybridRosenbrock kernel this way: an array the optimiser had
+made dynamically indexed; until round 4 up to 64 bytes were tolerated - the headline kernel sat at the 128-VGPR cap with
+12-32 B of it, part of which was reloaded in every step; now none does: COLD_SCRATCH_BYTES = 0); scratch elsewhere (the 1024-thread lane-split variants of the dim > 64 class spill a dozen VGPRs) is reported;
 if a production step kernel spills more SGPRs than PROD_SGPR_SPILL_CEILING (a ratchet: each spilled SGPR is a
 v_writelane / v_readlane pair in the step loop, and heavy SGPR spilling next to the empty-asm value barriers is the other
 ingredient of the register regime above); and if an object yields NO kernel at all (a different ROCm layout, a stripped
@@ -32,7 +32,7 @@ STREAM_SCRATCH_CEILING = 96  # bytes per thread, streaming twins (ratchet): wors
 MAX_KERNELS = 3200  # budget: every (target, proposal, width, twin) is a kernel to build, ship and keep correct (3 099 at the end of round 3, 3 387 with the streaming twins, 3 101 after retiring the 1024-thread lane-split class)
 MAX_LIBRARY_BYTES = 88 << 20  # budget for libptrwm_hip.so (--size, run by the Makefile after the link)
 STREAM_SGPR_SPILL_CEILING = 128  # the streaming twins (round 4; kernel.h STREAM): their own ratchet - the loop over groups keeps a dozen more scalars alive across the step than the classic kernel's single pass (worst when introduced: Hypercube<50> + UniformRadius, whose verdict is a chain of 64-bit lane masks)
-COLD_SCRATCH_BYTES = 64  # see the scratch rule in main()
+COLD_SCRATCH_BYTES = 0  # production step kernels of the max-ILP group: no scratch at all (64 until round 4, when the headline kernel still parked loop-invariant words - and, it turned out, two values it reloaded every step - there: profiles/r04_scratch_ab.txt)
 FIELDS = ("agpr_count", "vgpr_count", "vgpr_spill_count", "sgpr_count", "sgpr_spill_count", "private_segment_fixed_size",
           "group_segment_fixed_size")
 
