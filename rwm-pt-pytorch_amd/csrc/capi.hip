@@ -20,8 +20,8 @@ struct VariantPair {
 // ---- which form of the step kernel runs (quad.h) ------------------------------------------------------------------
 // The two forms are bit-identical on the same Philox stream, so this is a speed decision only; ptrwm_set_kernel_form()
 // pins it for tests and tuning.  AUTO compares a model of both forms' throughput at the launch's size
-// (tools/form_fit.py, fitted to profiles/r03_form_sweep_dense.txt - both forms timed over waves per SIMD, ladder lengths
-// and dims on one MI355X - and checked on a held-out sweep, profiles/r03_form_sweep_heldout.txt).  With w = wavefronts
+// (tools/form_fit.py, fitted to profiles/r04_form_sweep_dense.txt - both forms timed over waves per SIMD, ladder lengths
+// and dims on one MI355X - and checked on a held-out sweep, profiles/r04_form_sweep_heldout.txt).  With w = wavefronts
 // per SIMD the one-thread-per-replica form would launch:
 //   thread form   rate = A(k) w / k, k = ceil(w): a launch lasts as long as its fullest SIMDs, so at w = 1.25 the form
 //                 runs at 0.625 of its two-waves rate, not at its one-wave rate (the dips of profiles/r02_form_sweep.txt)

@@ -243,7 +243,7 @@ def test_the_binding_stub_printed_in_integration_md_has_the_c_layout(engine):
 
 def test_auto_form_rule_is_the_fitted_model(engine):
     """The form FORM_AUTO picks (ptrwm_auto_form; csrc/form_table.inc) is the model tools/form_fit.py fits to the committed
-    sweep of both forms (profiles/r03_form_sweep_dense.txt): the C++ evaluation and the Python one agree on a grid of
+    sweep of both forms (profiles/r04_form_sweep_dense.txt): the C++ evaluation and the Python one agree on a grid of
     dims, ladder lengths and batch sizes off the sweep's own points; on the sweep itself the rule always picks the
     faster form; and the saw-tooth is there (the thread form at 1.25 waves per SIMD is slower than at 1.0)."""
     import importlib.util
@@ -253,7 +253,7 @@ def test_auto_form_rule_is_the_fitted_model(engine):
     spec = importlib.util.spec_from_file_location("form_fit", os.path.join(root, "tools", "form_fit.py"))
     F = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(F)
-    tab = F.load(os.path.join(root, "profiles", "r03_form_sweep_dense.txt"))
+    tab = F.load(os.path.join(root, "profiles", "r04_form_sweep_dense.txt"))
     model = F.fit(tab)
     assert F.regret(model, tab, "fit data") > 0.99  # near-ties aside, the rule picks the faster form at every point of its own sweep
     simds = 1024  # an MI355X (256 CUs), stated to the library: ptrwm_auto_form_for is a pure function of its arguments

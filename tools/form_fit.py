@@ -1,7 +1,7 @@
 """Fits the AUTO form rule of csrc/capi.hip to a sweep of both kernel forms (tools/form_sweep.py dense) and writes it as a
 table (csrc/form_table.inc); given a second, held-out sweep, reports what AUTO would have cost there.
 
-    python tools/form_fit.py profiles/r03_form_sweep_dense.txt [held-out sweep] > csrc/form_table.inc   (table on stdout, report on stderr)
+    python tools/form_fit.py profiles/r04_form_sweep_dense.txt [held-out sweep] > csrc/form_table.inc   (table on stdout, report on stderr)
 
 The model.  w = wavefronts per SIMD the one-thread-per-replica form would launch.
   thread form:  rate(w) = A(k) * w / k,  k = ceil(w)     - a SIMD with k resident waves runs at A(k); with w < k on average,

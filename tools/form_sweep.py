@@ -33,13 +33,15 @@ def rate(dim, T, C, form, target_steps=2e9):
     return C * T * inner * 3 / (e0.elapsed_time(e1) * 1e-3)
 
 
-def dense(held_out=False):
+def dense(held_out=False, only_dims=None):
     """The table the AUTO rule of csrc/capi.hip is fitted on (and, with held_out, the one it is checked against): both
     pinned forms and AUTO over waves-per-SIMD of the thread form, ladder lengths and dims; one line per case."""
     ws = (0.6, 0.9, 1.1, 1.4, 1.6, 1.9, 2.2, 2.75, 3.5) if held_out else (0.25, 0.5, 0.75, 1.0, 1.25, 1.5, 1.75, 2.0, 2.5, 3.0, 4.0)
     # the fit grid: the dims with a kernel of their own (dim compiled in: 20, 30, 50) and, for all the others, dims across the
     # generic register widths; held out: other generic dims, and the compiled-in ones at other batch sizes
     dims = (18, 22, 26, 30, 38, 46, 50, 54, 62) if held_out else (16, 20, 24, 28, 30, 32, 36, 40, 44, 48, 50, 52, 56, 60, 64)
+    if only_dims:  # (a sweep can be cut into several GPU calls: python tools/form_sweep.py dense 16,20,24 ...; concatenate)
+        dims = tuple(d for d in dims if d in only_dims)
     print(f"# source_hash {E.source_hash()}")  # the kernels this sweep measures (tools/form_fit.py stamps the table with it)
     print(f"{'dim':>4} {'T':>4} {'chains':>7} {'w':>5} {'thread':>10} {'quad':>10} {'auto':>10} {'auto/best':>9}")
     worst = 1.0
@@ -56,7 +58,7 @@ def dense(held_out=False):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] in ("dense", "heldout"):
-        return dense(sys.argv[1] == "heldout")
+        return dense(sys.argv[1] == "heldout", [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else None)
     cases = [(30, 1, c) for c in (1024, 8192, 32768, 65536, 81920, 98304, 131072, 262144)] + \
             [(30, 8, c) for c in (1, 64, 1024, 4096, 8192, 16384, 32768)] + \
             [(30, 32, c) for c in (1, 64, 1024, 2048, 3072, 4096, 8192)] + \

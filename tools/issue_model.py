@@ -216,19 +216,24 @@ def main_cycles(a, name, header, path, pen, blocks, ops, valu, salu, ok, costs, 
     cyc = {k: v["cycles"] for k, v in costs.items()}
     sgpr_cost = sum(cyc[k] for k in SGPR_KEYS) / len(SGPR_KEYS)
     hist = collections.Counter()  # (opcode, class) -> count
+    sequence = []  # the step path in program order: [opcode, class] (tools/mix_probe.py replays it without dependencies)
     for b in path:
         for o, args in blocks[b]["ins"]:
             o = strip(o)
             if not o.startswith("v_"):
+                if o.startswith("s_") and not o.startswith(("s_waitcnt", "s_nop", "s_load", "s_buffer", "s_cbranch", "s_branch", "s_barrier")):
+                    sequence.append([o, "salu"])
                 continue
             if o in TRANS:
-                hist[(o, "quarter")] += 1
+                cls = "quarter"
             elif o in HALF or o.startswith("v_cmp"):
-                hist[(o, "half")] += 1
+                cls = "half"
             elif o in FULL:
-                hist[(o, "full+sgpr" if reads_sgpr(o, args) else "full")] += 1
+                cls = "full+sgpr" if reads_sgpr(o, args) else "full"
             else:
-                hist[(o, "unpriced")] += 1
+                cls = "unpriced"
+            hist[(o, cls)] += 1
+            sequence.append([o, cls, args])
     rows, floor, by_class, unpriced = [], 0.0, collections.Counter(), []
     for (o, cls), c in hist.most_common():
         if cls == "quarter":
@@ -257,7 +262,7 @@ def main_cycles(a, name, header, path, pen, blocks, ops, valu, salu, ok, costs, 
            "histogram_by_class": {f"{o} [{cls}]": c for (o, cls), c in hist.items()}, "class_counts": dict(by_class),
            "floor_cycles_per_wave_step": floor, "floor_cycles_per_valu_instruction": floor / n, "unpriced": sorted(set(unpriced)),
            "pmc_check": {"valu_per_wave_step": a.valu_per_wave_step, "salu_per_wave_step": a.salu_per_wave_step, "ok": ok},
-           "costs": os.path.relpath(a.costs, ROOT), "waves": a.waves, "lib_sha256": lib_sha}
+           "costs": os.path.relpath(a.costs, ROOT), "waves": a.waves, "lib_sha256": lib_sha, "sequence": sequence}
     if a.ns_per_wave_step and a.clock_ghz:
         meas = a.ns_per_wave_step * a.clock_ghz
         print(f"measured: {a.ns_per_wave_step:.1f} ns of SIMD time per wave-step x {a.clock_ghz:.3f} GHz = {meas:.0f} cycles = "
