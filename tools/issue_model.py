@@ -109,7 +109,8 @@ def kernel_blocks(asm_path, flt):
 def features(b):
     ops = [o for o, _ in b["ins"]]
     return {
-        "lds": sum(o.startswith("ds_") for o in ops), "barrier": sum(o == "s_barrier" for o in ops),
+        # (LDS traffic marks the swap event - except the no-return ds_add_f64 that every counted step adds its squared jump with)
+        "lds": sum(o.startswith("ds_") and not o.startswith("ds_add_f64") for o in ops), "barrier": sum(o == "s_barrier" for o in ops),
         "sload": sum(o.startswith("s_load") for o in ops), "inner": int("Depth=2" in b["notes"] or "Depth 2" in b["notes"] and "Child" not in b["notes"]),
         "global": sum(o.startswith(("global_", "flat_", "buffer_", "scratch_")) for o in ops),
         "cold": int("ptrwm-cold-path" in b["notes"]),  # PTRWM_COLD_PATH() of philox.h

@@ -73,7 +73,7 @@ def template(op, cls, k):
     raise SystemExit(f"mix_probe: no template for {op} [{cls}]")
 
 
-def rewrite(op, cls, args, k):
+def rewrite(op, cls, args, k, recent=0):
     """The instruction as the kernel has it - same encoding, operand kinds, literals and modifiers - with every register
     renamed so that nothing depends on anything: VGPR sources -> the constant pool, VGPR destinations -> the rotating pool,
     SGPR sources -> s40 / s[44:45], SGPR destinations -> s[42:43]; vcc stays vcc.  None if the shape is not understood
@@ -106,7 +106,10 @@ def rewrite(op, cls, args, k):
                 return None
         else:
             if re.match(r"^v\d+$", core):
-                core = src_regs[si % 4]
+                # (recent > 0: the first VGPR source is the result of the instruction `recent` places earlier - a dependency
+                # far enough back never to stall with four waves resident, but one the operand may arrive by without a
+                # register-file read, as most operands of the real step do)
+                core = f"v{(k - recent + 2) % N_DEST}" if (recent and si == 0) else src_regs[si % 4]
                 si += 1
             elif re.match(r"^v\[(\d+):(\d+)\]$", core):
                 a, b = map(int, re.match(r"^v\[(\d+):(\d+)\]$", core).groups())
@@ -143,11 +146,11 @@ def spread(seq):
 N_FALLBACK = [0]
 
 
-def body(seq):
+def body(seq, recent=0):
     lines = []
     for k, e in enumerate(seq):
         o, c = e[0], e[1]
-        t = rewrite(o, c, e[2], k) if len(e) > 2 else None
+        t = rewrite(o, c, e[2], k, recent) if len(e) > 2 else None
         if t is None:
             t = template(o, c, k)
             N_FALLBACK[0] += c != "salu"
@@ -162,7 +165,7 @@ def gen(model_json):
     clob = ", ".join(f'"v{i}"' for i in range(122)) + ', "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s48", "vcc", "scc"'
     init = "\n".join(f'      "v_mov_b32 v{CONST0 + i}, {0.3 + 0.01 * i:.2f}\\n"' for i in range(N_CONST))
 
-    def kernel(name, s):
+    def kernel(name, s, recent=0):
         return f"""__global__ void __launch_bounds__(256) {name}(unsigned long long *cyc, float *sink) {{
   const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
   asm volatile(
@@ -170,7 +173,7 @@ def gen(model_json):
       "s_mov_b32 s40, 0xD2511F53\\n s_mov_b32 s41, 0x9E3779B9\\n s_mov_b64 s[44:45], 0x5555\\n s_mov_b32 s46, 0\\n"
       "s_movk_i32 s48, {ITERS}\\n"
       "1:\\n"
-{body(s)}
+{body(s, recent)}
       "s_sub_i32 s48, s48, 1\\n s_cmp_lg_u32 s48, 0\\n s_cbranch_scc1 1b\\n"
       "v_mov_b32 v121, v0\\n"  // (122 VGPRs clobbered + the compiler's own: 128 allocated - the headline kernel's residency, four waves per SIMD)
       ::: {clob});
@@ -190,6 +193,7 @@ def gen(model_json):
 #include <vector>
 {kernel('mix_in_program_order', seq)}
 {kernel('mix_spread_evenly', spread(seq))}
+{kernel('mix_in_program_order_recent_sources', seq, 6)}
 template <class K>
 static void run(K k, const char *name, unsigned long long *dc, float *sink, bool last) {{
   const int blocks = 8192, waves = blocks * 4;
@@ -230,7 +234,8 @@ int main() {{
   (void)hipMalloc(&sink, 64);
   printf("{{\\n  \\"valu_per_iteration\\": {nv}, \\"salu_per_iteration\\": {len(seq) - nv}, \\"iterations\\": {ITERS}, \\"workgroups\\": 8192, \\"threads\\": 256,\\n");
   run(mix_in_program_order, "program_order", dc, sink, false);
-  run(mix_spread_evenly, "spread_evenly", dc, sink, true);
+  run(mix_spread_evenly, "spread_evenly", dc, sink, false);
+  run(mix_in_program_order_recent_sources, "program_order_first_source_is_a_recent_result", dc, sink, true);
   printf("}}\\n");
   return 0;
 }}

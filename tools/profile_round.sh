@@ -13,6 +13,8 @@ mkdir -p "$OUT"
 # (raw copy under $OUT: gpurun brings gpurun_out/ home, not profiles/ - tools/profile_summary.py and tools/issue_model.py are
 # then re-run at home on the raw output and write the same files under profiles/)
 if [ -x /root/repo/tools/issue_cost ]; then /root/repo/tools/issue_cost > "$OUT/issue_costs.json" 2> "$OUT/issue_cost.err" && cp "$OUT/issue_costs.json" /root/repo/profiles/${TAG}_issue_costs.json; fi
+# the issue time of the headline kernel's own instruction mix, replayed without dependencies (tools/mix_probe.py)
+if [ -x /root/repo/tools/mix_probe ]; then timeout -k 5 120 /root/repo/tools/mix_probe > "$OUT/mix_probe.json" 2> "$OUT/mix_probe.err" || true; fi
 cd /tmp
 export TMPDIR=/tmp
 B="python3 /root/repo/bench.py --cpu-seconds 0 --no-extras"
