@@ -1,6 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out
 L=$PWD/rwm-pt-pytorch_amd
-args=""
-for n in "" R15 R31 R15J3 R15J15 R15C; do args="$args D$n=$L/lib_exp$n/libptrwm_hip.so"; done
-timeout -k 10 1100 bash tools/ab_bench.sh $args
+timeout -k 10 1100 bash tools/ab_bench.sh N=$L/lib_exp/libptrwm_hip.so K3=$L/lib_expK3/libptrwm_hip.so W3=$L/lib_expW3/libptrwm_hip.so K4=$L/lib_expK4/libptrwm_hip.so
