@@ -605,14 +605,14 @@ int32_t ptrwm_last_launch_kind(void) { return t_last_launch_kind; }
 
 int32_t ptrwm_has_stream_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim) {
   if (ptrwm_has_thread_variant(target_kind, proposal_kind, dim) == 0) return 0;
-  const int dpi = width_index_for_dim(dim);
+  const int dpi = width_index_for_dim(dim, target_kind);
   return has_stream_variant(kWidths[dpi].dp, kWidths[dpi].exact) ? 1 : 0;
 }
 
 int32_t ptrwm_has_quad_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim, int32_t n_temps) {
   if (target_kind < 0 || target_kind >= PTRWM_TARGET_COUNT) return 0;
   if (proposal_kind < 0 || proposal_kind >= PTRWM_PROPOSAL_COUNT) return 0;
-  const int qi = quad_index_for(dim, n_temps);
+  const int qi = quad_index_for(dim, n_temps, target_kind);
   return qi >= 0 && quad_variants(target_kind, false).run[proposal_kind][qi] != nullptr ? 1 : 0;
 }
 
@@ -643,7 +643,7 @@ const char *ptrwm_form_table_source_hash(void) { return kFormTableSourceHash; }
 int32_t ptrwm_has_thread_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim) {
   if (target_kind < 0 || target_kind >= PTRWM_TARGET_COUNT) return 0;
   if (proposal_kind < 0 || proposal_kind >= PTRWM_PROPOSAL_COUNT) return 0;
-  const int dpi = width_index_for_dim(dim);
+  const int dpi = width_index_for_dim(dim, target_kind);
   return dim >= 1 && dpi >= 0 && target_variants(target_kind).run(proposal_kind, dpi) != nullptr ? 1 : 0;
 }
 
@@ -659,10 +659,10 @@ int32_t ptrwm_ext_raw_per_step(int32_t proposal_kind, int32_t dim) {
 int32_t ptrwm_has_variant(int32_t target_kind, int32_t proposal_kind, int32_t dim) {
   if (target_kind < 0 || target_kind >= PTRWM_TARGET_COUNT) return 0;
   if (proposal_kind < 0 || proposal_kind >= PTRWM_PROPOSAL_COUNT) return 0;
-  const int dpi = width_index_for_dim(dim);
+  const int dpi = width_index_for_dim(dim, target_kind);
   if (dim < 1 || dpi < 0) return 0;
   if (target_variants(target_kind).run(proposal_kind, dpi) != nullptr) return 1;
-  const int qi = quad_index_for(dim, 1);  // above width 64 the lane-split kernel is the fused kernel
+  const int qi = quad_index_for(dim, 1, target_kind);  // above width 64 the lane-split kernel is the fused kernel
   return qi >= 0 && quad_variants(target_kind, false).run[proposal_kind][qi] != nullptr ? 1 : 0;
 }
 
@@ -691,7 +691,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
                                  args->trace_every < 0))
     return PTRWM_E_ARG;
 
-  const int dpi = width_index_for_dim(target->dim);
+  const int dpi = width_index_for_dim(target->dim, target->kind);
   if (dpi < 0) return PTRWM_E_DIM;
   const bool two_term = (target->kind == PTRWM_TARGET_ROUGH_CARPET && rough_carpet_two_term(target->p)) ||
                         (target->kind == PTRWM_TARGET_THREE_MIXTURE && target->ip[0] == 1);  // the kind's specialised functor
@@ -700,7 +700,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
   // only form)
   bool quad = false;
   {
-    const int qi = quad_index_for(target->dim, args->n_temps);
+    const int qi = quad_index_for(target->dim, args->n_temps, target->kind);
     const QuadVariants &qv = quad_variants(target->kind, two_term);
     const RunLaunchFn qfn = qi >= 0 ? (f64 ? qv.run_f64 : qv.run)[proposal->kind][qi] : nullptr;
     const int form = __atomic_load_n(&g_kernel_form, __ATOMIC_RELAXED);
@@ -945,7 +945,7 @@ int32_t ptrwm_logdensity(const ptrwm_target_desc *target, const float *x, float 
   if (n < 0) return PTRWM_E_ARG;
   if (n == 0) return PTRWM_OK;
   if (x == nullptr || out == nullptr) return PTRWM_E_NULL;
-  const int dpi = width_index_for_dim(target->dim);
+  const int dpi = width_index_for_dim(target->dim, target->kind);
   if (dpi < 0) return PTRWM_E_DIM;
   // (RoughCarpet: the three-term functor always - the two-term one has the same bits where it applies; ThreeMixture1: a
   // different summation order, so a target declared that way is evaluated that way everywhere)

@@ -25,6 +25,12 @@ namespace ptrwm {
 // register width a dim maps to always has the dim's own canonical range width)
 #define PTRWM_WIDTHS_WIDE(X) X(100, true) X(80, false) X(96, false) X(104, false)
 #define PTRWM_WIDTHS(X) PTRWM_WIDTHS_NARROW(X) PTRWM_WIDTHS_WIDE(X)
+// Dims compiled in for ONE target only (round 4): the reference's HybridRosenbrock data uses dims 9, 19 and 29
+// (data/HybridRosenbrock_*_dim{9,19,29}_*), which no other family runs.  They sit BEHIND the common widths in every table
+// (so an index that was found without naming the target never reaches them), only the HybridRosenbrock translation units
+// instantiate them (PTRWM_TU_EXTRA_DIMS, null entries everywhere else), and a lookup finds them only for that target.
+#define PTRWM_WIDTHS_EXTRA(X) X(9, true) X(19, true) X(29, true)
+constexpr int kExtraDimsTarget = PTRWM_TARGET_HYBRID_ROSENBROCK;
 
 // The max-ILP group must stay at register widths <= 64 (at most 232 VGPRs measured): a wider entry belongs in
 // PTRWM_WIDTHS_WIDE.  (tools/kernel_stats.py --check, run by the Makefile, checks the compiled VGPR / AGPR counts too.)
@@ -39,16 +45,24 @@ PTRWM_WIDTHS_WIDE(PTRWM_X_WIDE_OK)
 struct WidthInfo {
   int dp;
   bool exact;
+  int only_target;  // -1: every target; else the one target that has this entry (PTRWM_WIDTHS_EXTRA)
 };
-#define PTRWM_X_INFO(W, E) {W, E},
-constexpr WidthInfo kWidths[] = {PTRWM_WIDTHS(PTRWM_X_INFO)};
+#define PTRWM_X_INFO(W, E) {W, E, -1},
+#define PTRWM_X_INFO_EXTRA(W, E) {W, E, kExtraDimsTarget},
+constexpr WidthInfo kWidths[] = {PTRWM_WIDTHS(PTRWM_X_INFO) PTRWM_WIDTHS_EXTRA(PTRWM_X_INFO_EXTRA)};
 #undef PTRWM_X_INFO
+#undef PTRWM_X_INFO_EXTRA
 constexpr int kNumWidths = (int)(sizeof(kWidths) / sizeof(kWidths[0]));
+#define PTRWM_X_EXTRA_OK(W, E) static_assert(E && W <= 64, "PTRWM_WIDTHS_EXTRA: dims compiled in, of the max-ILP group");
+PTRWM_WIDTHS_EXTRA(PTRWM_X_EXTRA_OK)
+#undef PTRWM_X_EXTRA_OK
 
-// exact width if one matches, else the narrowest generic width >= dim; -1 if none
-inline int width_index_for_dim(int dim) {
+// exact width if one matches (for this target: target_kind < 0 sees the common entries only), else the narrowest generic
+// width >= dim; -1 if none
+inline int width_index_for_dim(int dim, int target_kind = -1) {
   int best = -1;
   for (int i = 0; i < kNumWidths; ++i) {
+    if (kWidths[i].only_target >= 0 && kWidths[i].only_target != target_kind) continue;
     if (kWidths[i].exact) {
       if (kWidths[i].dp == dim) return i;
     } else if (kWidths[i].dp >= dim && (best < 0 || kWidths[i].dp < kWidths[best].dp)) {
@@ -182,15 +196,21 @@ hipError_t launch_logp(const float *x, float *out, long long n, int D, const TPa
 #define PTRWM_QUAD_WIDTHS(X)                                                                              \
   X(8, 0, kQuadThreads) X(8, 20, kQuadThreads) X(8, 30, kQuadThreads) X(16, 0, kQuadThreads) X(16, 50, kQuadThreads) \
   X(20, 0, kQuadThreads) X(24, 0, kQuadThreads) X(28, 0, kQuadThreads) X(28, 100, kQuadThreads)
+// (the lane-split twins of PTRWM_WIDTHS_EXTRA: one target only, behind the common entries)
+#define PTRWM_QUAD_WIDTHS_EXTRA(X) X(8, 9, kQuadThreads) X(8, 19, kQuadThreads) X(8, 29, kQuadThreads)
 struct QuadWidthInfo {
   int w, dexact, max_threads;
+  int only_target;  // -1: every target
 };
-#define PTRWM_X_QINFO(W, E, M) {W, E, M},
-constexpr QuadWidthInfo kQuadWidths[] = {PTRWM_QUAD_WIDTHS(PTRWM_X_QINFO)};
+#define PTRWM_X_QINFO(W, E, M) {W, E, M, -1},
+#define PTRWM_X_QINFO_EXTRA(W, E, M) {W, E, M, kExtraDimsTarget},
+constexpr QuadWidthInfo kQuadWidths[] = {PTRWM_QUAD_WIDTHS(PTRWM_X_QINFO) PTRWM_QUAD_WIDTHS_EXTRA(PTRWM_X_QINFO_EXTRA)};
 #undef PTRWM_X_QINFO
+#undef PTRWM_X_QINFO_EXTRA
 constexpr int kNumQuadWidths = (int)(sizeof(kQuadWidths) / sizeof(kQuadWidths[0]));
 #define PTRWM_X_QOK(W, E, M) static_assert(W == canon_width(4 * W) && (E == 0 || (E <= 4 * W && canon_width(E) == W)), "quad width table");
 PTRWM_QUAD_WIDTHS(PTRWM_X_QOK)
+PTRWM_QUAD_WIDTHS_EXTRA(PTRWM_X_QOK)
 #undef PTRWM_X_QOK
 
 // Exchange groups of the lane-split form.  4 T <= 64: one wavefront holds 16 / T whole ladders, four such groups per
@@ -219,12 +239,13 @@ inline int quad_block_threads(int n_temps) {
 
 // the kernel with this dim compiled in if there is one, else the generic kernel of the dim's class, in the smallest
 // workgroup class that holds the ladder; -1 if none
-inline int quad_index_for(int dim, int n_temps) {
+inline int quad_index_for(int dim, int n_temps, int target_kind = -1) {
   if (dim < 1 || dim > PTRWM_MAX_DIM || n_temps < 1) return -1;
   const int threads = quad_block_threads(n_temps);
   int best = -1;
   for (int i = 0; i < kNumQuadWidths; ++i) {
     const QuadWidthInfo &q = kQuadWidths[i];
+    if (q.only_target >= 0 && q.only_target != target_kind) continue;
     if (q.w != canon_width(dim) || q.max_threads < threads || (q.dexact != 0 && q.dexact != dim)) continue;
     if (best < 0) {
       best = i;
@@ -284,17 +305,26 @@ constexpr RunLaunchFn quad_f64_entry() {
 #define PTRWM_X_QRUN64_N(W, E, M) quad_f64_entry<QTGT<W, quad_min_own(W, E)>, QNormal<W, quad_min_own(W, E)>, W, E, M>(),
 #define PTRWM_X_QRUN64_L(W, E, M) quad_f64_entry<QTGT<W, quad_min_own(W, E)>, QLaplace<W, quad_min_own(W, E)>, W, E, M>(),
 #define PTRWM_X_QRUN64_U(W, E, M) quad_f64_entry<QTGT<W, quad_min_own(W, E)>, QUniformRadius<W, quad_min_own(W, E)>, W, E, M>(),
+// (the one-target entries: real kernels in the translation unit that defines PTRWM_TU_EXTRA_DIMS, null in every other)
+#define PTRWM_X_QNULL(W, E, M) nullptr,
+#ifdef PTRWM_TU_EXTRA_DIMS
+#define PTRWM_QUAD_EXTRA_ROW(X) PTRWM_QUAD_WIDTHS_EXTRA(X)
+#define PTRWM_EXTRA_ROW(X) PTRWM_WIDTHS_EXTRA(X)
+#else
+#define PTRWM_QUAD_EXTRA_ROW(X) PTRWM_QUAD_WIDTHS_EXTRA(PTRWM_X_QNULL)
+#define PTRWM_EXTRA_ROW(X) PTRWM_WIDTHS_EXTRA(PTRWM_X_NULL)
+#endif
 // One translation unit per target (csrc/quad_<target>.hip) defines its table with this macro.
 #define PTRWM_DEFINE_QUAD_VARIANTS(SYMBOL, QTARGET)                        \
   template <int W, int M>                                                  \
   using QTGT = QTARGET<W, M>;                                              \
   const QuadVariants &SYMBOL##_quad() {                                    \
-    static const QuadVariants v = {{{PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN_N)},   \
-                                    {PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN_L)},   \
-                                    {PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN_U)}},  \
-                                   {{PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN64_N)}, \
-                                    {PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN64_L)}, \
-                                    {PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN64_U)}}}; \
+    static const QuadVariants v = {{{PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN_N) PTRWM_QUAD_EXTRA_ROW(PTRWM_X_QRUN_N)},     \
+                                    {PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN_L) PTRWM_QUAD_EXTRA_ROW(PTRWM_X_QRUN_L)},     \
+                                    {PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN_U) PTRWM_QUAD_EXTRA_ROW(PTRWM_X_QRUN_U)}},    \
+                                   {{PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN64_N) PTRWM_QUAD_EXTRA_ROW(PTRWM_X_QRUN64_N)}, \
+                                    {PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN64_L) PTRWM_QUAD_EXTRA_ROW(PTRWM_X_QRUN64_L)}, \
+                                    {PTRWM_QUAD_WIDTHS(PTRWM_X_QRUN64_U) PTRWM_QUAD_EXTRA_ROW(PTRWM_X_QRUN64_U)}}}; \
     return v;                                                              \
   }
 
@@ -307,7 +337,7 @@ constexpr RunLaunchFn quad_f64_entry() {
 #define PTRWM_X_NULL(W, E) nullptr,
 #ifdef PTRWM_PART_WIDE
 #define PTRWM_PART_SUFFIX(SYMBOL) SYMBOL##_wide
-#define PTRWM_PART_ROW(X) PTRWM_WIDTHS_NARROW(PTRWM_X_NULL) PTRWM_WIDTHS_WIDE(X)
+#define PTRWM_PART_ROW(X) PTRWM_WIDTHS_NARROW(PTRWM_X_NULL) PTRWM_WIDTHS_WIDE(X) PTRWM_WIDTHS_EXTRA(PTRWM_X_NULL)
 // No one-thread-per-replica STEP kernels above width 64 (they needed 340-420 VGPRs, i.e. AGPR copies next to ~150 spilled
 // SGPRs: the regime in which hipcc produced wrong code twice - round 1 under max-ILP scheduling, round 2 under the default
 // scheduler after a fence moved; profiles/r02_miscompile_width80.txt): dim > 64 always runs the lane-split kernel
@@ -320,7 +350,7 @@ constexpr RunLaunchFn quad_f64_entry() {
 #define PTRWM_X_RUN_U(W, E) nullptr,
 #else
 #define PTRWM_PART_SUFFIX(SYMBOL) SYMBOL##_narrow
-#define PTRWM_PART_ROW(X) PTRWM_WIDTHS_NARROW(X) PTRWM_WIDTHS_WIDE(PTRWM_X_NULL)
+#define PTRWM_PART_ROW(X) PTRWM_WIDTHS_NARROW(X) PTRWM_WIDTHS_WIDE(PTRWM_X_NULL) PTRWM_EXTRA_ROW(X)
 #endif
 // Each object defines SYMBOL_narrow() or SYMBOL_wide(): a full-size table with null entries for the other group.
 #define PTRWM_DEFINE_TARGET_VARIANTS(SYMBOL, TARGET)                                   \

@@ -1,4 +1,5 @@
 // Instantiates the fused PT-RWM kernel for the HybridRosenbrock target (all proposals, all register widths).
+#define PTRWM_TU_EXTRA_DIMS  // this target also has kernels for PTRWM_WIDTHS_EXTRA (variants.h): its data dims 9, 19, 29
 #include "variants.h"
 
 namespace ptrwm {

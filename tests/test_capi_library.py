@@ -94,6 +94,13 @@ def test_validation_needs_no_gpu(engine):
             # one-thread-per-replica step kernels exist up to dim 64 only
             assert all(engine.has_thread_variant(t, p, d) for d in (1, 30, 50, 64))
             assert not any(engine.has_thread_variant(t, p, d) for d in (0, 65, 80, 100, 104, 105))
+    # streaming twins exist exactly where a one-thread-per-replica kernel has the dim compiled in: the common dims for
+    # every target, and 9 / 19 / 29 - the reference's HybridRosenbrock data dims - for that target alone (variants.h)
+    for t in range(10):
+        for p in range(3):
+            assert all(engine.has_stream_variant(t, p, d) for d in (2, 3, 4, 5, 10, 20, 30, 50))
+            assert not any(engine.has_stream_variant(t, p, d) for d in (1, 6, 8, 21, 31, 48, 64, 65, 100))
+            assert all(engine.has_stream_variant(t, p, d) == (t == engine.TARGET_HYBRID_ROSENBROCK) for d in (9, 19, 29))
     # the kernel-form switch: returns the previous setting, rejects unknown values
     assert engine.set_kernel_form(engine.FORM_QUAD) == engine.FORM_AUTO
     assert engine.set_kernel_form(engine.FORM_AUTO) == engine.FORM_QUAD

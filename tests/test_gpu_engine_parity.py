@@ -665,6 +665,63 @@ def test_generic_width_targets_vs_oracle(device, cls, dim, params, pkind):
     logp_close(got["trace_logp"], own, extra_abs=3e-4)
 
 
+# dim = 1 + n2 (n1 - 1): the dims of the reference's HybridRosenbrock data (data/HybridRosenbrock_*_dim{9,19,29}_*)
+HYBRID_DATA_DIMS = [(9, 3, 4), (19, 4, 6), (29, 5, 7)]
+
+
+@pytest.mark.parametrize("dim,n1,n2", HYBRID_DATA_DIMS)
+@pytest.mark.parametrize("pkind", ["Normal", "Laplace", "UniformRadius"])
+def test_hybrid_rosenbrock_data_dims_have_kernels_of_their_own(device, dim, n1, n2, pkind):
+    """Dims 9, 19 and 29 are compiled in for HybridRosenbrock ALONE (variants.h PTRWM_WIDTHS_EXTRA: entries behind the
+    common width table that only a lookup naming that target finds).  Visible through the ABI: the target has a streaming
+    twin there (only kernels with dim compiled in do), other targets at the same dim do not; and the kernels are the same
+    arithmetic - thread form and lane-split form against the oracle on shared randoms and on the production Philox path,
+    the two forms and the streaming form against each other bit for bit."""
+    params = {"a_coeff": np.float32(0.05), "b_coeff": np.float32(5), "mu": np.float32(1), "n1": n1, "n2": n2}
+    spec = H.spec_from_params("HybridRosenbrockTorch", dim, params)
+    T, Cn, N = 4, 16 * 3, 30
+    beta = np.float32([1.0, 0.5, 0.2, 0.05])
+    pkw = {"Normal": dict(base_variance_scalar=0.02), "Laplace": dict(base_variance_vector=np.full(dim, 0.02)),
+           "UniformRadius": dict(base_radius=float(np.sqrt(0.02 * (dim + 2))))}[pkind]
+    prop = H.proposal_spec(pkind, dim, beta, **pkw)
+    assert E.has_stream_variant(spec.kind, prop.kind, dim) == 1
+    other = H.spec_from_params("FullRosenbrockTorch", dim, {"a_coeff": np.float32(0.05), "b_coeff": np.float32(5),
+                                                           "mu": np.float32(np.ones(dim - 1))})
+    assert E.has_stream_variant(other.kind, prop.kind, dim) == 0 and E.has_variant(other.kind, prop.kind, dim) == 1
+    rng = np.random.default_rng(zlib.crc32(f"hybrid{dim}{pkind}".encode()))
+    st, lp = start_state(spec, Cn, T, rng)
+    raw = O.ext_raw_per_step(prop.kind, dim)
+    kw = dict(state=st, logp=lp, beta=beta, n_steps=N, burn_in=4, swap_every=5,
+              ext_prop=_ext_arrays(rng, pkind, N, Cn, T, raw), ext_u=rng.random((N, Cn, T)).astype(np.float32),
+              ext_swap_u=rng.random((N // 5, Cn, T - 1)).astype(np.float32))
+    keys = ("state", "logp", "n_accept", "sq_jump", "swap_accept", "last_swap_ordinal")
+    runs = {}
+    for form in (E.FORM_THREAD, E.FORM_QUAD):
+        with E.kernel_form(form):
+            H.check_parity(gpu_runner(spec, prop, device), H.oracle_runner(spec, prop), spec, prop,
+                           exact_states=pkind == "Normal", **kw)
+            H.check_parity_philox(gpu_runner(spec, prop, device), spec, prop, state=st, logp=lp, beta=beta, step0=5, n_steps=N,
+                                  burn_in=3, swap_every=4, seed=dim * 104729, chain_offset=3, segment=PHILOX_SEGMENT)
+            runs[form] = gpu_run(spec, prop, device, state=st, logp=lp, beta=beta, step0=5, n_steps=N, burn_in=3, swap_every=4,
+                                 seed=dim * 104729, chain_offset=3)
+            assert E.last_launch_kind() == (E.LAUNCH_THREAD if form == E.FORM_THREAD else E.LAUNCH_QUAD)
+    for k in keys:
+        assert np.array_equal(runs[E.FORM_THREAD][k], runs[E.FORM_QUAD][k]), k
+    # one-step launches through the streaming twin: the same bits as the classic kernel's
+    with E.kernel_form(E.FORM_THREAD):
+        a = b = dict(state=st, logp=lp)
+        for i in range(7):
+            with E.stream_mode(E.STREAM_OFF):
+                a = gpu_run(spec, prop, device, state=a["state"], logp=a["logp"], beta=beta, step0=i, n_steps=1, burn_in=2,
+                            swap_every=3, seed=11, chain_offset=0)
+            with E.stream_mode(E.STREAM_ON):
+                b = gpu_run(spec, prop, device, state=b["state"], logp=b["logp"], beta=beta, step0=i, n_steps=1, burn_in=2,
+                            swap_every=3, seed=11, chain_offset=0)
+                assert E.last_launch_kind() == E.LAUNCH_STREAM
+            for k in keys:
+                assert np.array_equal(a[k], b[k]), (k, i)
+
+
 @pytest.mark.parametrize("T,Cn", [(64, 3), (33, 2), (63, 5), (21, 4), (2, 100), (1, 1), (32, 1),
                                   (65, 2), (100, 3), (128, 1), (200, 2), (256, 2)])  # > 64: one ladder per workgroup
 def test_ladder_shapes_vs_oracle(device, T, Cn):

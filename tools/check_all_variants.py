@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rwm-pt-pytorch_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 f32 = np.float32
-WIDTH_DIMS = [2, 3, 4, 5, 10, 20, 30, 50, 100, 7, 15, 23, 31, 39, 47, 55, 63, 79, 103]  # exact widths, then W-1 per generic
+WIDTH_DIMS = [2, 3, 4, 5, 10, 20, 30, 50, 100, 9, 19, 29, 7, 15, 23, 31, 39, 47, 55, 63, 79, 103]  # exact widths (9 / 19 / 29: compiled in for HybridRosenbrock alone, generic kernels for the others), then W-1 per generic
 
 
 def make_spec(H, kind, dim, rng):
