@@ -427,3 +427,27 @@ def test_abi_calls_run_with_the_tensors_device_current(monkeypatch):
     for ln in calls:
         i = lines.index(ln)
         assert lines[i - 1].strip().startswith("with "), f"unguarded C-ABI call: {ln.strip()}"
+
+
+def test_every_tool_at_least_parses():
+    import os
+    """tools/ is tuning and evidence apparatus that the suites do not run (it needs a GPU and minutes per script); what can be
+    held here: every Python tool compiles, every shell tool passes `bash -n`, and every tool opens with a description."""
+    import glob
+    import py_compile
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tools = sorted(glob.glob(os.path.join(root, "tools", "*.py")) + glob.glob(os.path.join(root, "tools", "*.sh")))
+    assert len(tools) > 30
+    for path in tools:
+        if os.path.basename(path).startswith("_"):
+            continue  # scratch of a GPU call, not tracked
+        with open(path) as f:
+            head = f.read(400)
+        if path.endswith(".py"):
+            py_compile.compile(path, doraise=True)
+            assert head.lstrip().startswith(('"""', "'''", "#")), path
+        else:
+            assert subprocess.run(["bash", "-n", path]).returncode == 0, path
+            assert head.startswith("#!/bin/bash") and "\n#" in head, path
