@@ -349,6 +349,9 @@ __device__ __forceinline__ kargs_ptr late_args() {
 constexpr int min_waves_per_simd(int dp) {
   return dp <= 30 ? PTRWM_WAVES_SMALL : (dp <= 44 ? PTRWM_WAVES_40 : (dp <= 64 ? PTRWM_WAVES_MID : 1));
 }
+// the widths whose step loop fills the 128 VGPRs of four waves per SIMD (in the shipped table: the compiled-in dim 30, and 29
+// for HybridRosenbrock): what is loop-invariant there is recomputed rather than kept (ptrwm_step_kernel, the chain word)
+constexpr bool step_loop_at_register_cap(int dp, bool stream) { return !stream && min_waves_per_simd(dp) >= 4 && dp > 24; }
 
 // The streaming form (STREAM, below) keeps two slabs of rows per wave in LDS: fewer waves per SIMD fit (and each gets the
 // registers of that residency).
@@ -609,11 +612,12 @@ __global__ void __launch_bounds__(kBlockThreads, STREAM ? stream_register_waves(
     rc.c0hi = (uint32_t)(s >> 32) << 16;
     rc.c1 = (uint32_t)s;
     rc.c3 = c3_base | (kStreamMH << 8);
-    // (the chain word is made opaque per step: its product with the Philox multiplier is otherwise hoisted out of the step
-    // loop as a 64-bit pair, which at the register cap is spilled and fetched back from scratch at the top of every step -
-    // one v_mad_u64_u32 per step instead)
+    // (at the register cap the chain word is made opaque per step: its product with the Philox multiplier is otherwise
+    // hoisted out of the step loop as a 64-bit pair, which THERE is spilled and fetched back from scratch at the top of
+    // every step - one v_mad_u64_u32 per step instead.  Only there: every kernel with registers to spare keeps the hoisted
+    // product and runs 2-5 % faster for it - dims 24 / 48 / 50 in profiles/r04_scratch_ab.txt, table 6)
 #ifndef PTRWM_NO_C2_OPAQUE
-    asm volatile("" : "+v"(rc.c2));
+    if constexpr (step_loop_at_register_cap(DP, STREAM)) asm volatile("" : "+v"(rc.c2));
 #endif
 
     long long srep = 0;
