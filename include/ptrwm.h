@@ -36,6 +36,7 @@ extern "C" {
 #endif
 
 #define PTRWM_ABI_VERSION 3
+#define PTRWM_SPLIT_NO_SWEEP 1 /* ptrwm_run_args.split_flags, device-step mode: do not enqueue the swap kernel for this step */
 #define PTRWM_MAX_DIM 104  /* dim-vector lives in VGPRs; widest compiled variant */
 #define PTRWM_MAX_TEMPS 256 /* one ladder lives in one wavefront (<= 64 temps) or one workgroup; above dim 64 (lane-split
                               kernel only, 512-thread workgroups): at most 128, longer ladders get PTRWM_E_NOVARIANT */
@@ -254,14 +255,18 @@ typedef struct ptrwm_run_args {
    * float), uniforms, temperatures and proposal scales stay float.  ext_prop in this mode: NORMAL proposal only (the
    * reference's PT class is Gaussian only).  Always the lane-split form of the kernel; ladders of <= 128 temperatures. */
   int32_t state_f64;
-  int32_t reserved0; /* must be 0 */
+  int32_t split_flags; /* device-step mode of the split steps only (below); must be 0 everywhere else */
   /* Split steps only (ptrwm_split_propose / ptrwm_split_accept / ptrwm_split_advance; must be NULL for ptrwm_run and
-   * ptrwm_swap_sweep): device pointer to the 0-based index of the step to perform.  When set, the kernels read the step
-   * index from device memory instead of `step0` (which is ignored), derive burn-in and swap schedule from it on the
-   * device, and ptrwm_split_accept ALWAYS enqueues the swap kernel (it returns at once when no event is due): the argument
-   * list of a step no longer depends on the step, so a sequence of split steps - the caller's density evaluation
-   * included - can be captured ONCE in a HIP graph (torch.cuda.CUDAGraph) and replayed, with ptrwm_split_advance as
-   * the last node of every step.  External randoms (ext_prop / ext_u / ext_swap_u) are not available in this mode. */
+   * ptrwm_swap_sweep): device pointer to a step counter.  When set, the step a call performs is *device_step + step0 -
+   * the kernels read the counter from device memory, `step0` is an OFFSET baked into the call - and burn-in and swap
+   * schedule are derived from that on the device: the argument list of the k-th step of a block no longer depends on
+   * where the run stands, so a block of split steps - the caller's density evaluation included - can be captured ONCE in
+   * a HIP graph (torch.cuda.CUDAGraph) with step0 = 0, 1, ..., n - 1 and ONE ptrwm_split_advance (n_steps = n) as its last
+   * node, and replayed.  ptrwm_split_accept enqueues the swap kernel with every step (it returns at once when no event is
+   * due) unless split_flags has PTRWM_SPLIT_NO_SWEEP set: the caller's assertion that the step is NOT a swap step - its
+   * to keep (a caller that replays a block only from counters that are multiples of swap_every knows which offsets are
+   * swap steps; a wrong assertion loses the event silently).  External randoms (ext_prop / ext_u / ext_swap_u) are not
+   * available in this mode. */
   const int64_t *device_step;
 } ptrwm_run_args;
 
@@ -305,7 +310,8 @@ int32_t ptrwm_split_propose(const ptrwm_proposal_desc *proposal, const ptrwm_run
                             float *proposals, float *accept_u, void *stream);
 int32_t ptrwm_split_accept(const ptrwm_run_args *args, int32_t dim, float *proposals, const float *accept_u,
                            const float *logp_proposed, void *stream);
-/* *args->device_step += 1 on `stream` (one thread): the last node of a split step in device-step mode. */
+/* *args->device_step += max(1, args->n_steps) on `stream` (one thread): the last node of a block of split steps in
+ * device-step mode. */
 int32_t ptrwm_split_advance(const ptrwm_run_args *args, void *stream);
 
 /* out[i] = log_density(x[i, :]) for i < n; x is device [n, dim], out device [n]. */

@@ -43,7 +43,7 @@ class RunArgs(C.Structure):
         ("ext_prop", C.c_void_p), ("ext_u", C.c_void_p), ("ext_swap_u", C.c_void_p), ("trace", C.c_void_p),
         ("trace_logp", C.c_void_p), ("trace_chains", C.c_int64), ("trace_temps", C.c_int32),
         ("trace_every", C.c_int32), ("trace_row0", C.c_int64), ("accept_flags", C.c_void_p),
-        ("state_f64", C.c_int32), ("reserved0", C.c_int32), ("device_step", C.c_void_p),
+        ("state_f64", C.c_int32), ("split_flags", C.c_int32), ("device_step", C.c_void_p),
     ]
 
 

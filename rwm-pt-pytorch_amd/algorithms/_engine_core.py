@@ -155,12 +155,24 @@ class EngineRun:
     # same Philox words: bit-identical to the eager loop and (with the library's own density) to ptrwm_run.
     GRAPH_STEPS = 16
 
-    def _split_step_on_device_counter(self) -> None:
+    def _split_step_on_device_counter(self, offset: int = 0, no_sweep: bool = False, advance: int = 1) -> None:
+        """One split step at device step counter + offset; `advance` > 0 adds that much to the counter afterwards."""
         C, T, D = self.n_replicas, self.n_temps, self.dim
-        props = self._plan.split_propose(0)
+        props = self._plan.split_propose(offset)
         lp_new = self._density(props.view(-1, D)).view(C, T)
-        self._plan.split_accept(0, lp_new, swap_event_offset=self.manual_sweeps)
-        self._plan.split_advance()
+        self._plan.split_accept(offset, lp_new, swap_event_offset=self.manual_sweeps, no_sweep=no_sweep)
+        if advance:
+            self._plan.split_advance(advance)
+
+    def _graph_block(self) -> int:
+        """Steps per captured block: a multiple of swap_every (>= GRAPH_STEPS) where that is short enough, so that a block
+        replayed from a counter that is a multiple of swap_every has its swap steps at FIXED offsets and the swap kernel
+        is enqueued only there; GRAPH_STEPS otherwise (the swap kernel then rides with every step and decides on the
+        device)."""
+        se = int(self.swap_every)
+        if self.n_temps < 2 or se > 4 * self.GRAPH_STEPS:
+            return self.GRAPH_STEPS
+        return se * -(-self.GRAPH_STEPS // se)
 
     def _advance_split_graph(self, n_steps: int) -> bool:
         """n_steps split steps by graph replay; False if the density cannot be captured (the caller falls back)."""
@@ -170,9 +182,17 @@ class EngineRun:
             self._dstep = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._dstep.fill_(self.steps_done)
         self._plan.set_device_step(self._dstep)
+        block = self._graph_block()
+        aligned = self.n_temps >= 2 and block % int(self.swap_every) == 0  # swap steps sit at fixed offsets of a block
+        se = int(self.swap_every)
         try:
             done = 0
-            key = self.manual_sweeps  # (baked into the captured swap launch)
+
+            def eager(k):  # k steps, one at a time, on the device counter
+                for _ in range(k):
+                    self._split_step_on_device_counter()
+
+            key = (self.manual_sweeps, block)  # (baked into the captured launches)
             if getattr(self, "_graph_key", None) != key:
                 self._graph = None
             if self._graph is None:
@@ -185,28 +205,32 @@ class EngineRun:
                     self._split_step_on_device_counter()
                 cur.wait_stream(side)
                 done = 1
-                if n_steps - done >= self.GRAPH_STEPS:
-                    g = torch.cuda.CUDAGraph()
-                    try:
-                        with torch.cuda.graph(g):
-                            for _ in range(self.GRAPH_STEPS):
-                                self._split_step_on_device_counter()
-                    except Exception as e:  # a density that synchronises, allocates outside the pool, ...
-                        self._graph_failed = True
-                        torch.cuda.synchronize(self.device)
-                        warnings.warn(f"split steps: the density could not be captured in a HIP graph ({type(e).__name__}: {e}); "
-                                      "running step by step")
-                        self._dstep.fill_(self.steps_done + done)
-                        for _ in range(n_steps - done):
-                            self._split_step_on_device_counter()
-                        self.steps_done += n_steps
-                        return True
-                    self._graph, self._graph_key = g, key
-            while self._graph is not None and n_steps - done >= self.GRAPH_STEPS:
+            if aligned:  # replay only from counters that are multiples of swap_every
+                k = min(n_steps - done, (-(self.steps_done + done)) % se)
+                eager(k)
+                done += k
+            if self._graph is None and n_steps - done >= block:
+                g = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(g):
+                        for j in range(block):
+                            # step counter + j has step_counter = counter + j + 1: a swap step iff (j + 1) % swap_every == 0
+                            self._split_step_on_device_counter(offset=j, no_sweep=aligned and (j + 1) % se != 0,
+                                                               advance=block if j == block - 1 else 0)
+                except Exception as e:  # a density that synchronises, allocates outside the pool, ...
+                    self._graph_failed = True
+                    torch.cuda.synchronize(self.device)
+                    warnings.warn(f"split steps: the density could not be captured in a HIP graph ({type(e).__name__}: {e}); "
+                                  "running step by step")
+                    self._dstep.fill_(self.steps_done + done)
+                    eager(n_steps - done)
+                    self.steps_done += n_steps
+                    return True
+                self._graph, self._graph_key = g, key
+            while self._graph is not None and n_steps - done >= block:
                 self._graph.replay()
-                done += self.GRAPH_STEPS
-            for _ in range(n_steps - done):
-                self._split_step_on_device_counter()
+                done += block
+            eager(n_steps - done)
             self.steps_done += n_steps
             return True
         finally:

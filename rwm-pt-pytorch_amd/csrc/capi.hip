@@ -290,7 +290,7 @@ static TParams make_tparams(const ptrwm_target_desc *t) {
   return tp;
 }
 
-__global__ void split_advance_kernel(long long *device_step) { *device_step += 1; }
+__global__ void split_advance_kernel(long long *device_step, long long n) { *device_step += n; }
 
 __global__ void philox_raw_kernel(uint32_t *__restrict__ out, long long n, uint32_t c0, uint32_t c1, uint32_t c2,
                                   uint32_t c3, uint32_t k0, uint32_t k1) {
@@ -330,7 +330,7 @@ template <class state_t>
 __global__ void __launch_bounds__(256) swap_sweep_kernel(SweepArgs a) {
   if (a.device_step != nullptr) {
     // the swap event of step *device_step, if that step has one (ptrwm_split_accept's host-side rule, on the device)
-    const long long s0 = *a.device_step, sc = s0 + 1;
+    const long long s0 = *a.device_step + (long long)a.step, sc = s0 + 1;  // (a.step: this call's offset, include/ptrwm.h)
     if (!(sc > a.burn_in && sc % a.swap_every == 0)) return;  // (grid-uniform)
     a.step = (unsigned long long)s0;
     a.event_index = sc / a.swap_every - a.burn_in / a.swap_every - 1 + a.event_offset;
@@ -424,7 +424,8 @@ struct SplitAcceptArgs {
   unsigned char *accept_flags;
   long long n_reps;
   int n_temps, dim, count_on, swap_due;
-  const long long *device_step;  // device-step mode: count_on / swap_due are derived from *device_step
+  const long long *device_step;  // device-step mode: count_on / swap_due are derived from *device_step + step_offset
+  long long step_offset;
   long long burn_in, swap_every;
 };
 
@@ -438,7 +439,7 @@ __global__ void __launch_bounds__(64) split_accept_kernel(SplitAcceptArgs a) {
   const long long first = (long long)blockIdx.x * 64;
   if (first >= a.n_reps) return;
   if (a.device_step != nullptr) {
-    const long long sc = *a.device_step + 1;  // step_counter of this step
+    const long long sc = *a.device_step + a.step_offset + 1;  // step_counter of this step
     a.count_on = sc > a.burn_in;
     a.swap_due = a.n_temps > 1 && a.count_on && (sc % a.swap_every == 0);
   }
@@ -677,7 +678,7 @@ int32_t ptrwm_run(const ptrwm_target_desc *target, const ptrwm_proposal_desc *pr
     return PTRWM_E_ARG;
   if (args->swap_mode != PTRWM_SWAP_EXCHANGE && args->swap_mode != PTRWM_SWAP_REFERENCE_COPY) return PTRWM_E_ARG;
   if (args->swap_order != PTRWM_ORDER_SEQUENTIAL && args->swap_order != PTRWM_ORDER_EVEN_ODD) return PTRWM_E_ARG;
-  if ((args->state_f64 != 0 && args->state_f64 != 1) || args->reserved0 != 0 || args->device_step != nullptr) return PTRWM_E_ARG;
+  if ((args->state_f64 != 0 && args->state_f64 != 1) || args->split_flags != 0 || args->device_step != nullptr) return PTRWM_E_ARG;
   if (args->n_chains == 0 || args->n_steps == 0) return PTRWM_OK;  // empty batch: nothing to touch
   if (args->state == nullptr || args->logp == nullptr || args->beta == nullptr || proposal->temp_scale == nullptr)
     return PTRWM_E_NULL;
@@ -819,7 +820,7 @@ int32_t ptrwm_swap_sweep(const ptrwm_run_args *args, int32_t dim, int64_t event_
                          void *stream) {
   if (args == nullptr) return PTRWM_E_NULL;
   if (args->struct_size != sizeof(ptrwm_run_args)) return PTRWM_E_STRUCT;
-  if ((args->state_f64 != 0 && args->state_f64 != 1) || args->reserved0 != 0 || args->device_step != nullptr) return PTRWM_E_ARG;
+  if ((args->state_f64 != 0 && args->state_f64 != 1) || args->split_flags != 0 || args->device_step != nullptr) return PTRWM_E_ARG;
   if (dim < 1 || dim > PTRWM_MAX_DIM) return PTRWM_E_DIM;
   if (args->n_temps < 1 || args->n_temps > PTRWM_MAX_TEMPS) return PTRWM_E_TEMPS;
   if (args->n_chains < 0 || args->n_chains > 0x7fffffffll || args->step0 < 0 || event_index < 0 || rng_stream < 1 ||
@@ -835,7 +836,8 @@ int32_t ptrwm_swap_sweep(const ptrwm_run_args *args, int32_t dim, int64_t event_
 static int32_t split_common_checks(const ptrwm_run_args *args, int32_t dim) {
   if (args == nullptr) return PTRWM_E_NULL;
   if (args->struct_size != sizeof(ptrwm_run_args)) return PTRWM_E_STRUCT;
-  if (args->state_f64 != 0 || args->reserved0 != 0) return PTRWM_E_ARG;  // float states only
+  if (args->state_f64 != 0) return PTRWM_E_ARG;  // float states only
+  if ((args->split_flags & ~PTRWM_SPLIT_NO_SWEEP) != 0 || (args->split_flags != 0 && args->device_step == nullptr)) return PTRWM_E_ARG;
   if (dim < 1 || dim > PTRWM_MAX_DIM) return PTRWM_E_DIM;
   if (args->n_temps < 1 || args->n_temps > PTRWM_MAX_TEMPS) return PTRWM_E_TEMPS;
   if (args->n_chains < 0 || args->n_chains > 0x7fffffffll || args->step0 < 0 || args->burn_in < 0 ||
@@ -908,6 +910,7 @@ int32_t ptrwm_split_accept(const ptrwm_run_args *args, int32_t dim, float *propo
   a.count_on = count_on ? 1 : 0;
   a.swap_due = swap_due ? 1 : 0;
   a.device_step = (const long long *)args->device_step;
+  a.step_offset = args->step0;
   a.burn_in = args->burn_in;
   a.swap_every = args->swap_every;
   {
@@ -922,8 +925,9 @@ int32_t ptrwm_split_accept(const ptrwm_run_args *args, int32_t dim, float *propo
   }
   if (hipGetLastError() != hipSuccess) return PTRWM_E_LAUNCH;
   if (args->device_step != nullptr) {
-    // device-step mode: the sweep is enqueued with every step and decides on the device whether its event is due
-    if (args->n_temps < 2) return PTRWM_OK;
+    // device-step mode: the sweep is enqueued with every step and decides on the device whether its event is due - unless
+    // the caller vouches that this step has none (PTRWM_SPLIT_NO_SWEEP)
+    if (args->n_temps < 2 || (args->split_flags & PTRWM_SPLIT_NO_SWEEP) != 0) return PTRWM_OK;
     return launch_sweep(args, dim, 0, (int)kStreamSwap, proposals, args->sq_jump, (hipStream_t)stream);
   }
   if (!swap_due) return PTRWM_OK;
@@ -936,7 +940,8 @@ int32_t ptrwm_split_advance(const ptrwm_run_args *args, void *stream) {
   if (args == nullptr) return PTRWM_E_NULL;
   if (args->struct_size != sizeof(ptrwm_run_args)) return PTRWM_E_STRUCT;
   if (args->device_step == nullptr) return PTRWM_E_NULL;
-  hipLaunchKernelGGL(split_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long *)args->device_step);
+  hipLaunchKernelGGL(split_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long *)args->device_step,
+                     args->n_steps > 0 ? (long long)args->n_steps : 1ll);
   return hipGetLastError() == hipSuccess ? PTRWM_OK : PTRWM_E_LAUNCH;
 }
 

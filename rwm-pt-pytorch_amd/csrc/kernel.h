@@ -963,7 +963,7 @@ __global__ void __launch_bounds__(64, standalone_min_waves(DP)) ptrwm_split_prop
   const long long n_reps = n_chains * T;
   const long long first = (long long)blockIdx.x * 64;
   if (first >= n_reps) return;
-  if (device_step != nullptr) step = (unsigned long long)*device_step;  // (include/ptrwm.h: graph-capturable split steps)
+  if (device_step != nullptr) step += (unsigned long long)*device_step;  // (include/ptrwm.h: the counter plus this call's offset)
   const int n_rows = (n_reps - first < 64) ? (int)(n_reps - first) : 64;
   const bool live = lane < n_rows;
   const long long i = first + (live ? lane : 0);

@@ -114,7 +114,7 @@ class RunArgs(C.Structure):
         ("trace_row0", C.c_int64),
         ("accept_flags", C.c_void_p),
         ("state_f64", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("split_flags", C.c_int32),
         ("device_step", C.c_void_p),
     ]
 
@@ -601,9 +601,10 @@ class RunPlan:
 
     def set_device_step(self, counter: Optional[torch.Tensor]) -> None:
         """Device-step mode of the split-step calls (include/ptrwm.h `device_step`): ``counter`` is a one-element int64
-        device tensor holding the index of the step to perform; split_propose / split_accept then ignore their ``step``
-        argument, so their argument lists are the same for every step and a sequence of steps can be captured in a HIP
-        graph (``split_advance`` increments the counter as the last node of a step).  ``None`` switches it off."""
+        device tensor; split_propose / split_accept then perform step ``counter + step`` - their ``step`` argument is an
+        offset baked into the call - so the argument lists of a block of steps do not depend on where the run stands and
+        the block can be captured in a HIP graph (``split_advance(n)`` adds n to the counter as its last node).  ``None``
+        switches it off."""
         if counter is not None:
             if counter.numel() != 1 or counter.device != self.device:
                 raise ValueError("device_step must be a one-element int64 tensor on the run's device")
@@ -612,8 +613,11 @@ class RunPlan:
             self._a.device_step = None
         self._device_step = counter  # (kept alive)
 
-    def split_advance(self) -> None:
-        """*device_step += 1 on the current stream (ptrwm_split_advance)."""
+    def split_advance(self, n: int = 1) -> None:
+        """*device_step += n on the current stream (ptrwm_split_advance)."""
+        if n < 1:
+            raise ValueError("split_advance: n >= 1")
+        self._a.n_steps = n
         with self._guard:
             rc = self._lib.ptrwm_split_advance(self._refs[4], _stream(self.device))
         if rc != 0:
@@ -646,9 +650,10 @@ class RunPlan:
         return props
 
     def split_accept(self, step: int, logp_proposed: torch.Tensor, ext_swap_u: Optional[torch.Tensor] = None,
-                     accept_flags: Optional[torch.Tensor] = None, swap_event_offset: int = 0) -> None:
+                     accept_flags: Optional[torch.Tensor] = None, swap_event_offset: int = 0, no_sweep: bool = False) -> None:
         """Second half (ptrwm_split_accept): Metropolis rule on ``logp_proposed`` [C, T], updates, and the swap event
-        when ``step`` is a swap step."""
+        when ``step`` is a swap step.  ``no_sweep`` (device-step mode only, PTRWM_SPLIT_NO_SWEEP): the caller's assertion
+        that this step is not a swap step - the swap kernel is then not enqueued at all."""
         a = self._a
         Cn, T, D = self.shape
         props, acc_u = self._split_buffers()
@@ -660,14 +665,18 @@ class RunPlan:
             raise ValueError(f"accept_flags of one step must be [{Cn}, {T}]")
         a.step0 = step
         a.swap_event_offset = swap_event_offset
+        a.split_flags = 1 if no_sweep else 0
         self._last_trace = (None, None, None)
         a.ext_swap_u = _opt(ext_swap_u, "ext_swap_u", torch.float32)
         a.accept_flags = _opt(accept_flags, "accept_flags", torch.uint8)
         self._plain = False
-        with self._guard:
-            rc = self._lib.ptrwm_split_accept(self._refs[4], D, props.data_ptr(), acc_u.data_ptr(),
-                                              _require_device(logp_proposed, "logp_proposed", torch.float32),
-                                              _stream(self.device))
+        try:
+            with self._guard:
+                rc = self._lib.ptrwm_split_accept(self._refs[4], D, props.data_ptr(), acc_u.data_ptr(),
+                                                  _require_device(logp_proposed, "logp_proposed", torch.float32),
+                                                  _stream(self.device))
+        finally:
+            a.split_flags = 0  # (every other entry point requires 0)
         if rc != 0:
             raise PTRWMError(rc, "ptrwm_split_accept")
 

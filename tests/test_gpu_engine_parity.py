@@ -905,18 +905,21 @@ def test_split_step_reproduces_the_fused_kernel(device, tkey, pkind, T, pkw):
     ("hyb_5_4", "Normal", 1, dict(base_variance_scalar=0.02), "sequential", "exchange"),
 ])
 def test_split_steps_from_a_device_step_counter_and_a_captured_graph(device, tkey, pkind, T, pkw, order, mode):
-    """include/ptrwm.h `device_step`: with the step index in device memory no argument of a split step depends on the step,
-    so a block of steps - proposal kernel, the density's kernels, Metropolis kernel, swap kernel, counter increment - is
-    captured ONCE in a HIP graph and replayed.  Eager calls in device-step mode and graph replays both reproduce ptrwm_run
-    bit for bit (states, log-densities, all four statistics; burn-in and the swap schedule are derived from the counter on
-    the device), starting from a step index that is not zero."""
+    """include/ptrwm.h `device_step`: with a step counter in device memory the argument list of the k-th step of a block
+    does not depend on where the run stands (`step0` is an offset added to the counter), so a block of steps - proposal
+    kernel, the density's kernels, Metropolis kernel, swap kernel - is captured ONCE in a HIP graph with one counter
+    increment at its end and replayed.  Eager calls in device-step mode and graph replays both reproduce ptrwm_run bit for
+    bit (states, log-densities, all four statistics; burn-in and the swap schedule are derived from the counter on the
+    device), starting from a step index that is not zero.  The block starts at a multiple of swap_every, so the caller
+    knows which offsets are swap steps and asserts PTRWM_SPLIT_NO_SWEEP for the others: the swap kernel is not even
+    enqueued there."""
     spec = H.target_spec(tkey)
     D = spec.dim
     beta = (0.02 ** (np.arange(T) / max(1, T - 1))).astype(np.float32) if T > 1 else np.ones(1, np.float32)
     prop = H.proposal_spec(pkind, D, beta, **pkw) if T > 1 else H.proposal_spec(pkind, D, [1.0], single=True, **pkw)
     Cn, burn, se, s0 = 9, 7, 4, 3
-    K, replays, tail = 6, 4, 5  # steps per captured graph, replays, eager device-step steps behind them
-    N = 1 + K * replays + tail
+    K, replays, tail = 8, 3, 5  # steps per captured block (a multiple of swap_every), replays, eager steps behind them
+    N = 1 + K * replays + tail  # (s0 + 1 = 4: the block starts at a multiple of swap_every)
     st0, lp0 = start_state(spec, Cn, T, np.random.default_rng(zlib.crc32(tkey.encode())))
     kw = dict(beta=beta, burn_in=burn, swap_every=se, seed=321, chain_offset=2, swap_order=E.SWAP_ORDERS[order],
               swap_mode=E.SWAP_MODES[mode])
@@ -930,20 +933,22 @@ def test_split_steps_from_a_device_step_counter_and_a_captured_graph(device, tke
     counter = torch.full((1,), s0, dtype=torch.int64, device=device)
     plan.set_device_step(counter)
 
-    def step():
-        props = plan.split_propose(10**9)  # (the host-side step argument is ignored in this mode)
-        plan.split_accept(10**9, E.logdensity(tgt, props.view(-1, D)).view(Cn, T))
-        plan.split_advance()
+    def step(offset=0, no_sweep=False, advance=1):
+        props = plan.split_propose(offset)
+        plan.split_accept(offset, E.logdensity(tgt, props.view(-1, D)).view(Cn, T), no_sweep=no_sweep)
+        if advance:
+            plan.split_advance(advance)
 
     side = torch.cuda.Stream(device)
     side.wait_stream(torch.cuda.current_stream(device))
     with torch.cuda.stream(side):
         step()  # one step outside capture
     torch.cuda.current_stream(device).wait_stream(side)
+    assert (s0 + 1) % se == 0
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        for _ in range(K):
-            step()
+        for j in range(K):  # step counter + j: a swap step iff (j + 1) % swap_every == 0
+            step(offset=j, no_sweep=(j + 1) % se != 0, advance=K if j == K - 1 else 0)
     for _ in range(replays):
         g.replay()
     for _ in range(tail):
@@ -954,6 +959,10 @@ def test_split_steps_from_a_device_step_counter_and_a_captured_graph(device, tke
     for k, v in stats.items():
         assert np.array_equal(v.cpu().numpy(), fused[k]), k
     assert fused["n_accept"].sum() > 0 and (T == 1 or fused["swap_accept"].sum() > 0)
+    # the flag belongs to device-step mode: refused without a counter
+    plan.set_device_step(None)
+    with pytest.raises(E.PTRWMError):
+        plan.split_accept(0, lp, no_sweep=True)
     # the fused kernel and the stand-alone sweep refuse the field; external randoms are refused with it
     plan.set_device_step(counter)
     with pytest.raises(RuntimeError, match="device-step"):
