@@ -311,8 +311,9 @@ def main():
                 out[name] = {"value": n_rep * temps / (ms * 1e-3), "us_per_step": ms * 1e3}
                 del pt
             # bytes one chain-step moves through HBM, by the arrays each kernel reads and writes (an estimate: the density's
-            # intermediates are torch's): proposal kernel 8 D + 8, density 16 D + 4, Metropolis kernel 16 D + 56
-            per = 40 * dim + 68
+            # intermediates are torch's): proposal kernel 8 D + 8, density 16 D + 4, Metropolis kernel 12 D + 56 (state and
+            # proposals read, state written; the pre-step states are written back only on swap steps: + 0.4 D at swap_every 10)
+            per = 36.4 * dim + 68
             g = out["graph_replay"]
             g["bytes_per_chain_step_estimate"] = per
             g["GBps_estimate"] = g["value"] * per / 1e9

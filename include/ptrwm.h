@@ -301,7 +301,8 @@ int32_t ptrwm_swap_sweep(const ptrwm_run_args *args, int32_t dim, int64_t event_
  * `proposals` [n_chains, n_temps, dim] and `accept_u` [2, n_chains, n_temps] are device scratch owned by the caller
  * (accept_u plane 0: the accept uniforms; plane 1: the squared length of the increment as the fused kernel counts it -
  * the Philox paths of the Normal and UniformRadius proposals know it without a pass over the dimensions - or -1);
- * after ptrwm_split_accept `proposals` holds the states from before the step.  Driven with ptrwm_logdensity as the
+ * after ptrwm_split_accept of a SWAP step `proposals` holds the states from before the step (the swap kernel reads them);
+ * after any other step its contents are unspecified.  Driven with ptrwm_logdensity as the
  * density, a split step reproduces ptrwm_run bit for bit (tests/test_gpu_engine_parity.py) - state, log-densities and
  * counters always; sq_jump as ptrwm_run called one step at a time does: the split step takes the trust verdict of
  * ptrwm_run_args.sq_jump's comment from the state every step, ptrwm_run once per launch, so the two differ (within that

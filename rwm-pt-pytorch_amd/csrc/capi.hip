@@ -484,7 +484,9 @@ __global__ void __launch_bounds__(64) split_accept_kernel(SplitAcceptArgs a) {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   stage_copy<false>(xs, gx, n_rows * D, lane, 64);
-  stage_copy<false>(ys, gy, n_rows * D, lane, 64);
+  // the pre-step states go back in place of the proposals only where somebody reads them: the swap kernel of a swap step
+  // (its squared jump is |final - pre-step|^2).  A quarter of this kernel's HBM traffic on the other nine steps in ten.
+  if (a.swap_due) stage_copy<false>(ys, gy, n_rows * D, lane, 64);
   if (!live) return;
   if (acc) a.logp[i] = lp_new;
   if (a.accept_flags != nullptr) a.accept_flags[i] = acc ? 1 : 0;
